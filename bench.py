@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the FM-receiver hot path on MI355X.
+
+Metric (BASELINE.json): complex I/Q mega-samples per second through the
+receiver chain, per job (all GPUs), and the dominant kernel's fraction of the
+HBM roofline.
+
+Workload at N=1 = BASELINE.json configs[1]: mode 0 mono, 101-tap front-end
+FIR + decimate(10) + FM discriminator + 101-tap audio FIR + decimate(5) + s16
+pack, synthetic 2.4 MS/s FM I/Q, blocks of 1,024,000 complex samples.  One
+"step" = one pass of the whole chain over a device-resident batch of
+`--blocks` (default 256) consecutive blocks of one stream (0.5 GB of u8 I/Q),
+submitted as one block-parallel call (the mono chain is a sliding-window map of
+its input, SURVEY A.4, so this equals block-by-block streaming bit for bit --
+tests/test_gpu_parity.py::test_block_split_invariance_on_device).  Inputs are
+resident in HBM when the timed region starts; outputs (f32 audio + s16 PCM) are
+written to HBM.  N>1: one process per GPU, one independent channel per GPU
+(seed + rank), no data-path collective (RCCL is used only for the barrier and
+the max-over-ranks of the elapsed time): weak scaling.
+
+Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+BLOCK_SAMPLES = 1_024_000          # complex samples per block (= 20 reference blocks)
+HBM_PEAK_GBS = 8000.0              # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+# algorithmic HBM bytes per complex input sample of the front-end kernel (S1,
+# SURVEY 8d): 2 B of u8 I/Q in + 8/rf_decim B of float I,Q out
+FE_BYTES_PER_SAMPLE = 2.0 + 8.0 / 10.0
+FE_FLOP_PER_SAMPLE = 2 * 2 * 101 / 10.0
+
+
+def cpu_baseline(seconds: float = 10.0) -> dict:
+    """The oracle (C restatement of the reference, oracle/fm_oracle.c, -O3 like
+    src/Makefile:4) timed on this host: same chain, same taps, same signal.
+    Single thread = the reference-equivalent figure; then one independent
+    channel per available core."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from _oracle import Oracle  # checker library: allowed here (cpu_baseline leg) only
+    synth = importlib.import_module("software-defined-radio_amd.synth")
+    o = Oracle()
+    nblk_ref = 40                                        # 40 reference blocks = 2,048,000 samples per pass
+    iq = synth.synth_fm_u8(51200 * nblk_ref)
+
+    def run(budget_s: float, seed_off: int = 0) -> tuple[int, float]:
+        pl = o.pipeline(0, 1)
+        data = iq if seed_off == 0 else np.roll(iq, 2 * seed_off)
+        t0 = time.perf_counter()
+        done = 0
+        while True:
+            for b in range(nblk_ref):
+                pl.process(data[b * 102400:(b + 1) * 102400])
+            done += 51200 * nblk_ref
+            if time.perf_counter() - t0 >= budget_s:
+                break
+        return done, time.perf_counter() - t0
+
+    n1, t1 = run(seconds)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 64))
+    with ThreadPoolExecutor(cores) as ex:                # ctypes releases the GIL inside the C call
+        t0 = time.perf_counter()
+        res = list(ex.map(lambda c: run(seconds * 0.6, c + 1), range(cores)))
+        wall = time.perf_counter() - t0
+    return {
+        "value": round(n1 / t1 / 1e6, 2), "unit": "MS/s", "cores": 1, "kind": "port",
+        "sample": f"mode-0 mono chain (101/101 taps), {n1} complex samples in {t1:.1f} s, single thread, "
+                  "oracle/fm_oracle.c built -O3 (reference flags)",
+        "all_cores": {"value": round(sum(r[0] for r in res) / wall / 1e6, 2), "unit": "MS/s", "cores": cores,
+                      "sample": f"{cores} independent channels, one per core, {wall:.1f} s"},
+    }
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--blocks", type=int, default=256, help="1,024,000-sample blocks resident per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        print(json.dumps({"error": "no GPU visible; libfmrx has no CPU fallback"}))
+        return 2
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # control plane only: barrier + max of the elapsed time
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    fmrx = importlib.import_module("software-defined-radio_amd")
+    synth = importlib.import_module("software-defined-radio_amd.synth")
+
+    # ---- device-resident synthetic stream: this rank's channel ----
+    B = args.blocks
+    base_blocks = 4 if B % 4 == 0 else 1
+    iq_host = synth.synth_fm_u8(BLOCK_SAMPLES * base_blocks, 2.4e6, seed=0x3D74 + rank)
+    d_iq = torch.from_numpy(iq_host).cuda().repeat(B // base_blocks)       # [2 * B * 1,024,000] u8
+    n_bytes = d_iq.numel()
+    n_samples = n_bytes // 2
+    pl = fmrx.Pipeline(0, 1, rf_taps=101, base_audio_taps=101, max_block_bytes=n_bytes, device=local_rank)
+    n_audio = pl.n_audio(n_bytes)
+    d_audio = torch.empty(n_audio, dtype=torch.float32, device="cuda")
+    d_pcm = torch.empty(n_audio, dtype=torch.int16, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        pl.process_dev(d_iq.data_ptr(), n_bytes, d_audio.data_ptr(), d_pcm.data_ptr(), wrap=True, stream=stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    pl.set_profiling(True)       # HIP events around the front-end kernel, on the launch stream
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    tsum, cnt = pl.timing_sum(args.steps)
+    fe_ms = tsum["front_end_ms"] / cnt
+    pl.set_profiling(False)
+
+    out = None
+    if rank == 0:
+        total_samples = world * n_samples * args.steps
+        value = total_samples / elapsed / 1e6
+        fe_bytes = FE_BYTES_PER_SAMPLE * n_samples
+        achieved = fe_bytes / (fe_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "fe_traffic.json")   # PMC-derived bytes per launch, if collected
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if int(tj.get("blocks", -1)) == B:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "I/Q MS/s through front-end FIR+decimate+demod(+audio) per job; % HBM roofline",
+            "value": round(value, 1), "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "configs[1]: mode 0 mono, 101-tap FE FIR+decimate(10) + FM discriminator + 101-tap audio "
+                            "FIR+decimate(5) + s16 pack; synthetic 2.4 MS/s FM I/Q (u8), 1,024,000-sample blocks",
+                "blocks_per_step": B, "samples_per_step_per_gpu": n_samples,
+                "sharding": f"{world} independent channel(s), one per GPU, no collective",
+                "realtime_channels_equiv": round(value / 2.4, 0),
+            },
+            "roofline": {
+                "kernel": "fe_fir_kernel<101,10,8,256> (u8 I/Q -> 101-tap FIR -> decimate 10 -> f32 I,Q)",
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": int(fe_bytes), "avg_launch_ms": round(fe_ms, 4),
+                "launches_timed": cnt,
+                "fp32_tflops": round(FE_FLOP_PER_SAMPLE * n_samples / (fe_ms * 1e-3) / 1e12, 2),
+                "stage_ms": {k: round(v / cnt, 4) for k, v in tsum.items()},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,253 @@
+/*
+ * fmrx.h -- C ABI of libfmrx.so: the MI355X (gfx950) implementation of the
+ * FM-receiver DSP hot path of mnigm2001/Software-Defined-Radio.
+ *
+ * This header is the drop-in boundary.  The reference has no FFI layer; its
+ * operator API for this path is the set of C++ free functions declared in
+ * include/filter.h:18-43 and include/iofunc.h:36 (std::vector<float>&
+ * arguments), plus the stdin/stdout process contract of src/project.cpp and
+ * src/threadMonoOnly.cpp.  Each entry point below names the reference
+ * interface it replaces (file:line under /root/reference).  A header-only C++
+ * shim (include/fmrx_filter.hpp) re-exposes the exact filter.h signatures on
+ * top of this ABI; INTEGRATION.md shows the binding a maintainer would add.
+ *
+ * Conventions
+ *  - plain pointers + explicit lengths, no C++ or torch types;
+ *  - every function returns an fmrx_status (0 = ok); nothing calls exit();
+ *    fmrx_last_error() gives the message for the calling thread;
+ *  - caller owns every buffer; outputs are caller-allocated to the sizes the
+ *    reference's functions resize() to (stated per function);
+ *  - "state" buffers are in/out and have exactly the reference's layout;
+ *  - the reference's unchecked preconditions (n >= taps-1, n % decim == 0 for
+ *    cross-block continuity, taps <= 65535) are validated: FMRX_EINVAL;
+ *  - all compute runs on the GPU (HIP kernels).  There is NO CPU fallback:
+ *    with no usable device the compute entry points return FMRX_ENODEV.
+ *    Only the filter-coefficient design (a3/a4), which is host code in the
+ *    reference too and runs once per run, executes on the host;
+ *  - functions with a `_dev` suffix take DEVICE pointers and a HIP stream
+ *    (passed as void* so this header needs no HIP include) and are
+ *    asynchronous on that stream; all others take HOST pointers and are
+ *    synchronous (internally H2D -> kernels -> D2H on the current device);
+ *  - re-entrant; a pipeline handle is single-owner (not thread-safe), handles
+ *    on different devices (= channels) are independent.
+ */
+#ifndef FMRX_H
+#define FMRX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define FMRX_API __attribute__((visibility("default")))
+#else
+#define FMRX_API
+#endif
+
+typedef enum fmrx_status {
+    FMRX_OK = 0,
+    FMRX_EINVAL = 1, /* bad argument / violated precondition */
+    FMRX_ENODEV = 2, /* no usable HIP device (never falls back to the CPU) */
+    FMRX_EHIP = 3,   /* HIP runtime error */
+    FMRX_ENOMEM = 4
+} fmrx_status;
+
+/* ------------------------------------------------------------------ */
+/* library                                                              */
+/* ------------------------------------------------------------------ */
+FMRX_API const char *fmrx_version(void);
+FMRX_API const char *fmrx_last_error(void);
+/* number of HIP devices visible to the process (0 when there is none) */
+FMRX_API int fmrx_device_count(void);
+/* select the device used by the host-pointer stage functions of this thread */
+FMRX_API int fmrx_set_device(int device);
+
+/* ------------------------------------------------------------------ */
+/* filter-coefficient API (host, float32 bit-compatible)                */
+/* ------------------------------------------------------------------ */
+/* replaces impulseResponseLPF  include/filter.h:24, src/filter.cpp:103-114.
+ * h[num_taps]. */
+FMRX_API int fmrx_impulse_response_lpf(float Fs, float Fc, unsigned short num_taps, float *h);
+/* replaces bandPass  include/filter.h:20, src/filter.cpp:83-99.  h[num_taps]. */
+FMRX_API int fmrx_band_pass(float Fs, float Fb, float Fe, unsigned short num_taps, float *h);
+
+/* ------------------------------------------------------------------ */
+/* stage API on host buffers: one call per reference primitive          */
+/* ------------------------------------------------------------------ */
+/* replaces readStdinBlockData's conversion  include/iofunc.h:36,
+ * src/iofunc.cpp:128-135: out[k] = (raw[k]-128)/128.  out[n]. */
+FMRX_API int fmrx_u8_to_f32(const uint8_t *raw, size_t n, float *out);
+/* replaces the I/Q split  src/project.cpp:98-105.  I[n_pairs], Q[n_pairs]. */
+FMRX_API int fmrx_deinterleave(const float *iq, size_t n_pairs, float *I, float *Q);
+/* replaces convolveFIR  include/filter.h:26, src/filter.cpp:118-130.
+ * y[n + taps - 1]. */
+FMRX_API int fmrx_convolve_fir(float *y, const float *x, size_t n, const float *h, size_t taps);
+/* replaces convolveBlockFIR  include/filter.h:28-29, src/filter.cpp:133-154.
+ * y[n]; state[taps-1] in/out.  Requires n >= taps-1. */
+FMRX_API int fmrx_convolve_block_fir(float *y, const float *x, size_t n, const float *h, size_t taps, float *state);
+/* replaces convolveBlockFastFIR  include/filter.h:31-32,
+ * src/filter.cpp:158-188.  y[n / decim]; state[taps-1] in/out.
+ * Requires n >= taps-1, decim >= 1. */
+FMRX_API int fmrx_convolve_block_fast_fir(float *y, const float *x, size_t n, const float *h, size_t taps,
+                                          float *state, unsigned decim);
+/* replaces convolveBlockResampleFIR  include/filter.h:34-35,
+ * src/filter.cpp:191-223.  y[(n*upsamp)/decim]; state[taps-1] in/out in the
+ * reference's upsampled index space (slots == upsamp-1 mod upsamp are live).
+ * Output gain is (1+upsamp), as in the reference (:213).
+ * Requires n*upsamp >= taps-1. */
+FMRX_API int fmrx_convolve_block_resample_fir(float *y, const float *x, size_t n, const float *h, size_t taps,
+                                              float *state, unsigned decim, unsigned upsamp);
+/* replaces upsample / downsample  include/filter.h:37-39,
+ * src/filter.cpp:227-245.  xu[n*up];  out[ceil(n/ds)] (count via *n_out). */
+FMRX_API int fmrx_upsample(const float *x, size_t n, float *xu, int up);
+FMRX_API int fmrx_downsample(float *out, size_t *n_out, const float *in, size_t n, unsigned short ds);
+/* replaces fmDemod  include/filter.h:41, src/filter.cpp:248-266.  out[n];
+ * *prev_i / *prev_q in/out. */
+FMRX_API int fmrx_fm_demod(float *out, const float *I, const float *Q, size_t n, float *prev_i, float *prev_q);
+/* replaces allPass  include/filter.h:18, src/filter.cpp:14-29 (note the
+ * reference's argument order: in, state, out).  out[n]; state[nstate] in/out;
+ * requires n >= nstate. */
+FMRX_API int fmrx_all_pass(const float *in, size_t n, float *state, size_t nstate, float *out);
+/* replaces fmPLL  include/filter.h:22, src/filter.cpp:32-80.  nco_out[n+1];
+ * state[6] = {integrator, phaseEst, feedbackI, feedbackQ, lastOut, trigOffset}. */
+FMRX_API int fmrx_fm_pll(const float *in, size_t n, float *nco_out, float *state, float freq, float Fs,
+                         float ncoScale, float phaseAdjust, float normBandwidth);
+/* replaces the mixer and L/R combine loops  src/project.cpp:246-248, 277-280 */
+FMRX_API int fmrx_stereo_mix(const float *stereo_filt, const float *pll, size_t n, float *mixer);
+FMRX_API int fmrx_stereo_combine(const float *stereo_final, const float *mono, size_t n, float *left, float *right);
+/* replaces the PCM writer's conversion  src/threadMonoOnly.cpp:185-191:
+ * NaN -> 0 else (short)(a*16384).  wrap != 0 reproduces the compiled
+ * reference on overflow (int32 truncation, low 16 bits); wrap == 0 saturates. */
+FMRX_API int fmrx_pcm16(const float *audio, size_t n, int16_t *out, int wrap);
+
+/* ------------------------------------------------------------------ */
+/* mode table and pipeline handle                                       */
+/* ------------------------------------------------------------------ */
+/* replaces struct PARAMS + the mode table  src/project.cpp:17-27, 424-427
+ * and the block-size rule :55-57 */
+typedef struct fmrx_params {
+    int mode;         /* 0..3 */
+    int rf_Fs, if_Fs; /* Hz */
+    float audio_Fs;
+    int rf_decim, audio_decim, audio_upsamp; /* upsamp 0 = integer decimation */
+    int rf_taps;
+    int audio_taps;   /* already multiplied by audio_upsamp for modes 2, 3 */
+    int stereo_taps;
+    int block_bytes;  /* the reference's per-mode stdin block size */
+} fmrx_params;
+
+/* base_audio_taps: 101 (src/threadMonoOnly.cpp:229-232) or 13
+ * (src/project.cpp:424-427); rf_taps: 101 / 151 / 13. */
+FMRX_API int fmrx_mode_params(int mode, int rf_taps, int base_audio_taps, int stereo_taps, fmrx_params *p);
+
+typedef struct fmrx_pipeline fmrx_pipeline;
+
+/* PCM overflow policy for s16 outputs */
+#define FMRX_PCM_WRAP 1     /* what the compiled reference does */
+#define FMRX_PCM_SATURATE 0
+
+/* replaces main()'s setup + the RF_FrontEnd / RF_MONO / RF_STEREO thread
+ * bodies  src/project.cpp:40-152, 154-309, 311-382, 385-500.
+ * channels: 1 mono, 2 stereo.  max_block_bytes: the largest block that will
+ * be passed to process (device buffers are sized once, here).  device: HIP
+ * device ordinal.  The handle owns all device memory and the carried state
+ * (I/Q FIR history, prev I/Q, audio FIR histories, all-pass delay, PLL). */
+FMRX_API int fmrx_pipeline_create(fmrx_pipeline **out, const fmrx_params *p, int channels, size_t max_block_bytes,
+                                  int device);
+FMRX_API int fmrx_pipeline_destroy(fmrx_pipeline *pl);
+/* restore the all-zero initial state of src/project.cpp:61-65, 446-458 */
+FMRX_API int fmrx_pipeline_reset(fmrx_pipeline *pl);
+FMRX_API size_t fmrx_pipeline_n_if(const fmrx_pipeline *pl, size_t n_bytes);
+FMRX_API size_t fmrx_pipeline_n_audio(const fmrx_pipeline *pl, size_t n_bytes);
+
+/* One block, host buffers: iq[n_bytes] interleaved u8 I,Q (the stdin format,
+ * src/iofunc.cpp:128-135) -> audio.  Any of the outputs may be NULL.
+ *   audio_f32 : mono [n_audio], or stereo left then right planar [2*n_audio]
+ *   pcm16     : mono [n_audio], or stereo interleaved L,R [2*n_audio]
+ *               (the layout of the writer at src/project.cpp:292-302)
+ * n_bytes must satisfy the reference's divisibility rules for the mode
+ * (n_bytes/2 % rf_decim == 0, n_if % audio_decim == 0 or
+ * n_if*upsamp % decim == 0) and n_bytes/2 >= rf_taps-1. */
+FMRX_API int fmrx_pipeline_process(fmrx_pipeline *pl, const uint8_t *iq, size_t n_bytes, float *audio_f32,
+                                   int16_t *pcm16, int pcm_policy);
+/* Same, device-resident: d_iq is DEVICE memory (16-byte aligned), outputs are
+ * DEVICE memory or NULL; asynchronous on `stream` (a hipStream_t).  This is
+ * the entry point the throughput figures are measured on. */
+FMRX_API int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_bytes, float *d_audio_f32,
+                                       int16_t *d_pcm16, int pcm_policy, void *stream);
+/* Copies of the last block's device intermediates to host, for parity tests
+ * and diagnostics.  which: see FMRX_TAP_*.  out may be NULL to query *n. */
+#define FMRX_TAP_IF_I 0
+#define FMRX_TAP_IF_Q 1
+#define FMRX_TAP_DEMOD 2
+#define FMRX_TAP_MONO 3
+#define FMRX_TAP_CARRIER 4
+#define FMRX_TAP_STEREO_BPF 5
+#define FMRX_TAP_PLL 6
+#define FMRX_TAP_MIXER 7
+#define FMRX_TAP_STEREO_FINAL 8
+FMRX_API int fmrx_pipeline_read_tap(fmrx_pipeline *pl, int which, float *out, size_t *n);
+/* carried state, serialised: floats in the order
+ *   I_state[rf_taps-1], Q_state[rf_taps-1], prev_i, prev_q, state_mono[Ha]
+ *   (+ stereo: state_stereo[St-1], state_carrier[St-1], state_stereofilt[Ha],
+ *    state_allpass[(St-1)/2], state_PLL[6])
+ * where Ha = audio history in INPUT samples (audio_taps-1, or
+ * (audio_taps-1)/upsamp for modes 2,3).  n = number of floats. */
+FMRX_API size_t fmrx_pipeline_state_size(const fmrx_pipeline *pl);
+FMRX_API int fmrx_pipeline_get_state(fmrx_pipeline *pl, float *state, size_t n);
+FMRX_API int fmrx_pipeline_set_state(fmrx_pipeline *pl, const float *state, size_t n);
+/* wall-clock free: device time of the kernels of the last process call, ms,
+ * per stage (HIP events on the pipeline's stream).  t[4] = {front_end, audio,
+ * stereo_extra, total}. */
+FMRX_API int fmrx_pipeline_last_timing(fmrx_pipeline *pl, float *t);
+/* sums of the same four figures over the most recent profiled calls (at most
+ * max_calls, at most the 128 the handle keeps); *count = calls summed */
+FMRX_API int fmrx_pipeline_timing_sum(fmrx_pipeline *pl, float *t, int *count, int max_calls);
+/* enable (1) / disable (0) the per-stage HIP events behind last_timing */
+FMRX_API int fmrx_pipeline_set_profiling(fmrx_pipeline *pl, int on);
+/* force the parameter-generic kernels (1) or allow the specialised ones (0) */
+FMRX_API int fmrx_pipeline_set_force_generic(fmrx_pipeline *pl, int on);
+
+/* ------------------------------------------------------------------ */
+/* fused front end (the hot kernel) as a stage of its own               */
+/* ------------------------------------------------------------------ */
+/* Fused: u8 I/Q -> (u8-128)/128 -> rf low-pass FIR -> decimate, I and Q
+ * together.  Replaces readStdinBlockData's conversion (src/iofunc.cpp:133),
+ * the I/Q split (src/project.cpp:98-105) and the two convolveBlockFastFIR
+ * calls of RF_FrontEnd (src/project.cpp:111,121; src/filter.cpp:158-188).
+ *
+ * Host buffers, synchronous:
+ *   iq[2*n_samples]   interleaved u8 I,Q
+ *   hist              in/out, 2*(taps-1) bytes: the taps-1 complex samples that
+ *                     precede the block (the reference's I_state/Q_state, kept
+ *                     as raw u8); NULL = start of stream (silence), no carry
+ *   if_i, if_q        out, n_samples/decim floats each (either may be NULL)
+ * force_generic != 0 runs the parameter-generic kernel (reference evaluation
+ * order, bit-compatible) instead of the specialised one. */
+FMRX_API int fmrx_fe_fir_decim_u8(const uint8_t *iq, size_t n_samples, const float *h, size_t taps, unsigned decim,
+                                  uint8_t *hist, float *if_i, float *if_q, int force_generic);
+
+/* Device buffers, asynchronous on a HIP stream: a reusable plan holds the tap
+ * tables on the device. */
+typedef struct fmrx_fe_plan fmrx_fe_plan;
+FMRX_API int fmrx_fe_plan_create(fmrx_fe_plan **out, const float *h, size_t taps, unsigned decim);
+FMRX_API int fmrx_fe_plan_destroy(fmrx_fe_plan *plan);
+/* 1 when a specialised (register-window, packed-FMA) kernel exists for the
+ * plan's (taps, decim); 0 when it will run the generic kernel */
+FMRX_API int fmrx_fe_plan_is_specialised(const fmrx_fe_plan *plan);
+/* bytes of history the kernel reads in front of a block: 2*(taps-1) rounded up
+ * to a multiple of 16; the LAST 2*(taps-1) bytes are the previous samples */
+FMRX_API size_t fmrx_fe_plan_history_bytes(const fmrx_fe_plan *plan);
+/* d_iq: DEVICE, 16-byte aligned, 2*n_samples bytes.  d_hist: DEVICE,
+ * history_bytes bytes, or NULL for silence.  d_if: DEVICE, interleaved float
+ * I,Q, n_samples/decim pairs.  stream: hipStream_t (NULL = default stream). */
+FMRX_API int fmrx_fe_run_dev(const fmrx_fe_plan *plan, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist,
+                             float *d_if, int force_generic, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FMRX_H */

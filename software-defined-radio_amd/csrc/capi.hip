@@ -1,0 +1,417 @@
+// capi.hip -- the extern "C" layer of libfmrx.so (include/fmrx.h): library
+// functions and the host-buffer stage API, one entry point per reference
+// primitive (include/filter.h:18-43, include/iofunc.h:36 under /root/reference).
+//
+// Every stage function: validate (the reference's unchecked preconditions
+// become FMRX_EINVAL) -> H2D into per-thread scratch -> HIP kernel(s) -> D2H.
+// No stage has a CPU implementation: without a device they return FMRX_ENODEV.
+#include "fmrx_internal.hpp"
+
+namespace fmrx {
+
+// ---- error plumbing ----------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int require_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(FMRX_ENODEV, "no usable HIP device (%s); libfmrx has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    }
+    return FMRX_OK;
+}
+
+namespace {
+
+// per-thread device scratch for the host-buffer stage functions
+struct Scratch {
+    DevBuf<float> a, b, c, d, h;
+    DevBuf<uint8_t> u, uh;
+    DevBuf<int16_t> s16;
+};
+Scratch &scratch()
+{
+    static thread_local Scratch s;
+    return s;
+}
+
+inline int h2d(void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0) return FMRX_OK;
+    FMRX_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return FMRX_OK;
+}
+inline int d2h(void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0) return FMRX_OK;
+    FMRX_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return FMRX_OK;
+}
+inline int sync0()
+{
+    FMRX_HIP(hipStreamSynchronize(nullptr));
+    return FMRX_OK;
+}
+
+}  // namespace
+}  // namespace fmrx
+
+using namespace fmrx;
+
+extern "C" {
+
+const char *fmrx_version(void) { return "fmrx 0.1 (gfx950)"; }
+const char *fmrx_last_error(void) { return g_err; }
+
+int fmrx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int fmrx_set_device(int device)
+{
+    FMRX_TRY(require_device());
+    FMRX_HIP(hipSetDevice(device));
+    return FMRX_OK;
+}
+
+// ---- element-wise stages ---------------------------------------------------------
+int fmrx_u8_to_f32(const uint8_t *raw, size_t n, float *out)
+{
+    if ((!raw || !out) && n) return fail(FMRX_EINVAL, "u8_to_f32: null buffer");
+    FMRX_TRY(require_device());
+    Scratch &s = scratch();
+    FMRX_TRY(s.u.ensure(n));
+    FMRX_TRY(s.a.ensure(n));
+    FMRX_TRY(h2d(s.u.p, raw, n));
+    FMRX_TRY(k_u8_to_f32(s.u.p, n, s.a.p, nullptr));
+    return d2h(out, s.a.p, n * sizeof(float));
+}
+
+int fmrx_deinterleave(const float *iq, size_t n_pairs, float *I, float *Q)
+{
+    if ((!iq || !I || !Q) && n_pairs) return fail(FMRX_EINVAL, "deinterleave: null buffer");
+    FMRX_TRY(require_device());
+    Scratch &s = scratch();
+    FMRX_TRY(s.a.ensure(2 * n_pairs));
+    FMRX_TRY(s.b.ensure(n_pairs));
+    FMRX_TRY(s.c.ensure(n_pairs));
+    FMRX_TRY(h2d(s.a.p, iq, 2 * n_pairs * sizeof(float)));
+    FMRX_TRY(k_deinterleave(s.a.p, n_pairs, s.b.p, s.c.p, nullptr));
+    FMRX_TRY(d2h(I, s.b.p, n_pairs * sizeof(float)));
+    return d2h(Q, s.c.p, n_pairs * sizeof(float));
+}
+
+int fmrx_pcm16(const float *audio, size_t n, int16_t *out, int wrap)
+{
+    if ((!audio || !out) && n) return fail(FMRX_EINVAL, "pcm16: null buffer");
+    FMRX_TRY(require_device());
+    Scratch &s = scratch();
+    FMRX_TRY(s.a.ensure(n));
+    FMRX_TRY(s.s16.ensure(n));
+    FMRX_TRY(h2d(s.a.p, audio, n * sizeof(float)));
+    FMRX_TRY(k_pcm16(s.a.p, n, s.s16.p, wrap, nullptr));
+    return d2h(out, s.s16.p, n * sizeof(int16_t));
+}
+
+// ---- FIR family -----------------------------------------------------------------------
+// device layout for a block with carried history: [history | block], kernels get
+// a pointer to the block and read history at negative indices.
+static int fir_common(float *y, size_t n_out, const float *x, size_t n, const float *h, size_t taps,
+                      const float *state, size_t n_hist, size_t n_tail_zero, unsigned decim)
+{
+    Scratch &s = scratch();
+    FMRX_TRY(s.a.ensure(n_hist + n + n_tail_zero));
+    FMRX_TRY(s.h.ensure(taps));
+    FMRX_TRY(s.b.ensure(n_out));
+    if (state) FMRX_TRY(h2d(s.a.p, state, n_hist * sizeof(float)));
+    else FMRX_HIP(hipMemset(s.a.p, 0, n_hist * sizeof(float)));
+    FMRX_TRY(h2d(s.a.p + n_hist, x, n * sizeof(float)));
+    if (n_tail_zero) FMRX_HIP(hipMemset(s.a.p + n_hist + n, 0, n_tail_zero * sizeof(float)));
+    FMRX_TRY(h2d(s.h.p, h, taps * sizeof(float)));
+    FMRX_TRY(k_fir_generic(s.a.p + n_hist, n_out, s.h.p, static_cast<int>(taps), static_cast<int>(decim), s.b.p, nullptr));
+    return d2h(y, s.b.p, n_out * sizeof(float));
+}
+
+int fmrx_convolve_fir(float *y, const float *x, size_t n, const float *h, size_t taps)
+{
+    if (!y || !x || !h || taps == 0 || n == 0) return fail(FMRX_EINVAL, "convolve_fir: bad arguments");
+    if (taps > 65535) return fail(FMRX_EINVAL, "convolve_fir: taps %zu > 65535", taps);
+    FMRX_TRY(require_device());
+    // full convolution = block FIR over [0^(taps-1) | x | 0^(taps-1)]
+    return fir_common(y, n + taps - 1, x, n, h, taps, nullptr, taps - 1, taps - 1, 1);
+}
+
+static int block_fir(const char *name, float *y, const float *x, size_t n, const float *h, size_t taps, float *state,
+                     unsigned decim)
+{
+    if (!y || !x || !h || !state || taps == 0) return fail(FMRX_EINVAL, "%s: null buffer", name);
+    if (decim == 0) return fail(FMRX_EINVAL, "%s: decim must be >= 1", name);
+    if (taps > 65535) return fail(FMRX_EINVAL, "%s: taps %zu > 65535 (unsigned short in the reference)", name, taps);
+    if (n < taps - 1)
+        return fail(FMRX_EINVAL, "%s: block of %zu samples is shorter than taps-1 = %zu (state refresh would read before the block)",
+                    name, n, taps - 1);
+    FMRX_TRY(require_device());
+    FMRX_TRY(fir_common(y, n / decim, x, n, h, taps, state, taps - 1, 0, decim));
+    // state <- last taps-1 samples of x (src/filter.cpp:148-153, 182-187): a host copy in the reference too
+    std::memcpy(state, x + n - (taps - 1), (taps - 1) * sizeof(float));
+    return FMRX_OK;
+}
+
+int fmrx_convolve_block_fir(float *y, const float *x, size_t n, const float *h, size_t taps, float *state)
+{
+    return block_fir("convolve_block_fir", y, x, n, h, taps, state, 1);
+}
+
+int fmrx_convolve_block_fast_fir(float *y, const float *x, size_t n, const float *h, size_t taps, float *state,
+                                 unsigned decim)
+{
+    return block_fir("convolve_block_fast_fir", y, x, n, h, taps, state, decim);
+}
+
+int fmrx_convolve_block_resample_fir(float *y, const float *x, size_t n, const float *h, size_t taps, float *state,
+                                     unsigned decim, unsigned upsamp)
+{
+    if (!y || !x || !h || !state || taps == 0) return fail(FMRX_EINVAL, "convolve_block_resample_fir: null buffer");
+    if (decim == 0 || upsamp == 0) return fail(FMRX_EINVAL, "convolve_block_resample_fir: decim and upsamp must be >= 1");
+    if (taps > 65535) return fail(FMRX_EINVAL, "convolve_block_resample_fir: taps %zu > 65535", taps);
+    if (n * upsamp < taps - 1)
+        return fail(FMRX_EINVAL, "convolve_block_resample_fir: n*upsamp = %zu < taps-1 = %zu", n * upsamp, taps - 1);
+    FMRX_TRY(require_device());
+    // The reference keeps its state in the UPSAMPLED index space: stream sample
+    // x[-d] (d = 1..H) lives in state[taps-1 - d*upsamp]  (src/filter.cpp:207, 218-222).
+    const size_t H = (taps - 1) / upsamp;
+    std::vector<float> hist(H ? H : 1, 0.0f);
+    for (size_t d = 1; d <= H; d++) hist[H - d] = state[taps - 1 - d * upsamp];
+    Scratch &s = scratch();
+    const size_t n_out = (n * upsamp) / decim;
+    FMRX_TRY(s.a.ensure(H + n));
+    FMRX_TRY(s.h.ensure(taps));
+    FMRX_TRY(s.b.ensure(n_out));
+    FMRX_TRY(h2d(s.a.p, hist.data(), H * sizeof(float)));
+    FMRX_TRY(h2d(s.a.p + H, x, n * sizeof(float)));
+    FMRX_TRY(h2d(s.h.p, h, taps * sizeof(float)));
+    FMRX_TRY(k_resample_generic(s.a.p + H, n, s.h.p, static_cast<int>(taps), static_cast<int>(decim),
+                                static_cast<int>(upsamp), s.b.p, nullptr));
+    FMRX_TRY(d2h(y, s.b.p, n_out * sizeof(float)));
+    // state refresh exactly as src/filter.cpp:218-222 (host copy): k = U-1; for
+    // i = U*n-(taps-1); i < U*n-U; i += U: state[k] = x[i/U + 1]; k += U
+    {
+        const long U = upsamp, ns = static_cast<long>(taps) - 1, N = static_cast<long>(n);
+        long k = U - 1;
+        for (long i = U * N - ns; i < U * N - U; i += U) {
+            state[k] = x[(i / U) + 1];
+            k += U;
+        }
+    }
+    return FMRX_OK;
+}
+
+int fmrx_upsample(const float *x, size_t n, float *xu, int up)
+{
+    if ((!x || !xu) && n) return fail(FMRX_EINVAL, "upsample: null buffer");
+    if (up < 1) return fail(FMRX_EINVAL, "upsample: rate must be >= 1");
+    FMRX_TRY(require_device());
+    Scratch &s = scratch();
+    FMRX_TRY(s.a.ensure(n));
+    FMRX_TRY(s.b.ensure(n * up));
+    FMRX_TRY(h2d(s.a.p, x, n * sizeof(float)));
+    FMRX_TRY(k_upsample(s.a.p, n, s.b.p, up, nullptr));
+    return d2h(xu, s.b.p, n * up * sizeof(float));
+}
+
+int fmrx_downsample(float *out, size_t *n_out, const float *in, size_t n, unsigned short ds)
+{
+    if (!out || !in || !n_out) return fail(FMRX_EINVAL, "downsample: null buffer");
+    if (ds == 0) return fail(FMRX_EINVAL, "downsample: factor must be >= 1");
+    FMRX_TRY(require_device());
+    // size rule of src/filter.cpp:240: ceil(n / (float)ds), evaluated in float
+    const size_t ny = static_cast<size_t>(ceilf(static_cast<float>(n) / static_cast<float>(ds)));
+    *n_out = ny;
+    Scratch &s = scratch();
+    FMRX_TRY(s.a.ensure(n + ds));
+    FMRX_TRY(s.b.ensure(ny));
+    FMRX_TRY(h2d(s.a.p, in, n * sizeof(float)));
+    FMRX_TRY(k_downsample(s.a.p, ny, s.b.p, ds, nullptr));
+    return d2h(out, s.b.p, ny * sizeof(float));
+}
+
+// ---- demod / stereo helpers -----------------------------------------------------------
+int fmrx_fm_demod(float *out, const float *I, const float *Q, size_t n, float *prev_i, float *prev_q)
+{
+    if (!out || !I || !Q || !prev_i || !prev_q) return fail(FMRX_EINVAL, "fm_demod: null buffer");
+    if (n == 0) return FMRX_OK;
+    FMRX_TRY(require_device());
+    Scratch &s = scratch();
+    FMRX_TRY(s.a.ensure(n));
+    FMRX_TRY(s.b.ensure(n));
+    FMRX_TRY(s.c.ensure(n));
+    FMRX_TRY(h2d(s.a.p, I, n * sizeof(float)));
+    FMRX_TRY(h2d(s.b.p, Q, n * sizeof(float)));
+    FMRX_TRY(k_fm_demod_planar(s.a.p, s.b.p, n, *prev_i, *prev_q, s.c.p, nullptr));
+    FMRX_TRY(d2h(out, s.c.p, n * sizeof(float)));
+    *prev_i = I[n - 1];
+    *prev_q = Q[n - 1];
+    return FMRX_OK;
+}
+
+int fmrx_all_pass(const float *in, size_t n, float *state, size_t nstate, float *out)
+{
+    if (!in || !state || !out) return fail(FMRX_EINVAL, "all_pass: null buffer");
+    if (n < nstate) return fail(FMRX_EINVAL, "all_pass: block of %zu samples shorter than the delay %zu", n, nstate);
+    FMRX_TRY(require_device());
+    Scratch &s = scratch();
+    FMRX_TRY(s.a.ensure(n));
+    FMRX_TRY(s.b.ensure(nstate));
+    FMRX_TRY(s.c.ensure(n));
+    FMRX_TRY(h2d(s.a.p, in, n * sizeof(float)));
+    FMRX_TRY(h2d(s.b.p, state, nstate * sizeof(float)));
+    FMRX_TRY(k_all_pass(s.a.p, n, s.b.p, nstate, s.c.p, nullptr));
+    FMRX_TRY(d2h(out, s.c.p, n * sizeof(float)));
+    std::memcpy(state, in + n - nstate, nstate * sizeof(float));
+    return FMRX_OK;
+}
+
+int fmrx_fm_pll(const float *in, size_t n, float *nco_out, float *state, float freq, float Fs, float ncoScale,
+                float phaseAdjust, float normBandwidth)
+{
+    if (!in || !nco_out || !state) return fail(FMRX_EINVAL, "fm_pll: null buffer");
+    if (!(Fs > 0)) return fail(FMRX_EINVAL, "fm_pll: Fs must be positive");
+    FMRX_TRY(require_device());
+    Scratch &s = scratch();
+    FMRX_TRY(s.a.ensure(n));
+    FMRX_TRY(s.b.ensure(n + 1));
+    FMRX_TRY(s.c.ensure(6));
+    FMRX_TRY(h2d(s.a.p, in, n * sizeof(float)));
+    FMRX_TRY(h2d(s.c.p, state, 6 * sizeof(float)));
+    FMRX_TRY(k_fm_pll(s.a.p, n, s.b.p, s.c.p, freq, Fs, ncoScale, phaseAdjust, normBandwidth, nullptr));
+    FMRX_TRY(d2h(nco_out, s.b.p, (n + 1) * sizeof(float)));
+    return d2h(state, s.c.p, 6 * sizeof(float));
+}
+
+int fmrx_stereo_mix(const float *stereo_filt, const float *pll, size_t n, float *mixer)
+{
+    if ((!stereo_filt || !pll || !mixer) && n) return fail(FMRX_EINVAL, "stereo_mix: null buffer");
+    FMRX_TRY(require_device());
+    Scratch &s = scratch();
+    FMRX_TRY(s.a.ensure(n));
+    FMRX_TRY(s.b.ensure(n));
+    FMRX_TRY(s.c.ensure(n));
+    FMRX_TRY(h2d(s.a.p, stereo_filt, n * sizeof(float)));
+    FMRX_TRY(h2d(s.b.p, pll, n * sizeof(float)));
+    FMRX_TRY(k_mix(s.a.p, s.b.p, n, s.c.p, nullptr));
+    return d2h(mixer, s.c.p, n * sizeof(float));
+}
+
+int fmrx_stereo_combine(const float *stereo_final, const float *mono, size_t n, float *left, float *right)
+{
+    if ((!stereo_final || !mono || !left || !right) && n) return fail(FMRX_EINVAL, "stereo_combine: null buffer");
+    FMRX_TRY(require_device());
+    Scratch &s = scratch();
+    FMRX_TRY(s.a.ensure(n));
+    FMRX_TRY(s.b.ensure(n));
+    FMRX_TRY(s.c.ensure(n));
+    FMRX_TRY(s.d.ensure(n));
+    FMRX_TRY(h2d(s.a.p, stereo_final, n * sizeof(float)));
+    FMRX_TRY(h2d(s.b.p, mono, n * sizeof(float)));
+    FMRX_TRY(k_combine(s.a.p, s.b.p, n, s.c.p, s.d.p, nullptr));
+    FMRX_TRY(d2h(left, s.c.p, n * sizeof(float)));
+    return d2h(right, s.d.p, n * sizeof(float));
+}
+
+// ---- fused front end as a stage ----------------------------------------------------------
+struct fmrx_fe_plan {
+    FePlan plan;
+};
+
+int fmrx_fe_plan_create(fmrx_fe_plan **out, const float *h, size_t taps, unsigned decim)
+{
+    if (!out || !h) return fail(FMRX_EINVAL, "fe_plan_create: null argument");
+    if (taps < 2 || taps > 65535) return fail(FMRX_EINVAL, "fe_plan_create: taps %zu not in 2..65535", taps);
+    if (decim == 0) return fail(FMRX_EINVAL, "fe_plan_create: decim must be >= 1");
+    FMRX_TRY(require_device());
+    fmrx_fe_plan *p = new fmrx_fe_plan;
+    int rc = fe_plan_init(p->plan, h, static_cast<int>(taps), static_cast<int>(decim));
+    if (rc != FMRX_OK) {
+        delete p;
+        return rc;
+    }
+    *out = p;
+    return FMRX_OK;
+}
+
+int fmrx_fe_plan_destroy(fmrx_fe_plan *plan)
+{
+    delete plan;
+    return FMRX_OK;
+}
+
+int fmrx_fe_plan_is_specialised(const fmrx_fe_plan *plan) { return plan && plan->plan.fast ? 1 : 0; }
+size_t fmrx_fe_plan_history_bytes(const fmrx_fe_plan *plan) { return plan ? plan->plan.hist_bytes : 0; }
+
+int fmrx_fe_run_dev(const fmrx_fe_plan *plan, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist, float *d_if,
+                    int force_generic, void *stream)
+{
+    if (!plan || !d_iq || !d_if) return fail(FMRX_EINVAL, "fe_run_dev: null argument");
+    return fe_launch(plan->plan, d_iq, n_samples, d_hist, d_if, static_cast<hipStream_t>(stream), force_generic != 0);
+}
+
+int fmrx_fe_fir_decim_u8(const uint8_t *iq, size_t n_samples, const float *h, size_t taps, unsigned decim, uint8_t *hist,
+                         float *if_i, float *if_q, int force_generic)
+{
+    if (!iq || !h) return fail(FMRX_EINVAL, "fe_fir_decim_u8: null buffer");
+    if (taps < 2 || taps > 65535) return fail(FMRX_EINVAL, "fe_fir_decim_u8: taps %zu not in 2..65535", taps);
+    if (decim == 0) return fail(FMRX_EINVAL, "fe_fir_decim_u8: decim must be >= 1");
+    if (hist && n_samples < taps - 1)
+        return fail(FMRX_EINVAL, "fe_fir_decim_u8: block of %zu samples shorter than taps-1 = %zu", n_samples, taps - 1);
+    FMRX_TRY(require_device());
+    FePlan plan;
+    FMRX_TRY(fe_plan_init(plan, h, static_cast<int>(taps), static_cast<int>(decim)));
+    Scratch &s = scratch();
+    const size_t n_out = n_samples / decim;
+    const size_t hb = plan.hist_bytes, live = 2 * (taps - 1);
+    FMRX_TRY(s.u.ensure(2 * n_samples));
+    FMRX_TRY(s.uh.ensure(hb));
+    FMRX_TRY(s.a.ensure(2 * n_out));
+    FMRX_TRY(s.b.ensure(n_out));
+    FMRX_TRY(s.c.ensure(n_out));
+    FMRX_TRY(h2d(s.u.p, iq, 2 * n_samples));
+    if (hist) {
+        FMRX_TRY(k_fill_u8(s.uh.p, hb, 128, nullptr));
+        FMRX_TRY(h2d(s.uh.p + (hb - live), hist, live));
+    }
+    FMRX_TRY(fe_launch(plan, s.u.p, n_samples, hist ? s.uh.p : nullptr, s.a.p, nullptr, force_generic != 0));
+    FMRX_TRY(k_split_if(s.a.p, n_out, s.b.p, s.c.p, nullptr));
+    if (if_i) FMRX_TRY(d2h(if_i, s.b.p, n_out * sizeof(float)));
+    if (if_q) FMRX_TRY(d2h(if_q, s.c.p, n_out * sizeof(float)));
+    FMRX_TRY(sync0());
+    if (hist) std::memcpy(hist, iq + 2 * n_samples - live, live);  // carry: the last taps-1 samples, as bytes
+    return FMRX_OK;
+}
+
+}  // extern "C"

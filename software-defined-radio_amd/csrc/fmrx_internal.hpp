@@ -1,0 +1,130 @@
+// fmrx_internal.hpp -- shared declarations for libfmrx.so (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "fmrx.h"
+
+namespace fmrx {
+
+// ---- error plumbing -------------------------------------------------------
+void set_error(const char *fmt, ...);
+int fail(int code, const char *fmt, ...);
+
+#define FMRX_HIP(expr)                                                                         \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return ::fmrx::fail(FMRX_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                __FILE__, __LINE__);                                           \
+    } while (0)
+
+#define FMRX_TRY(expr)              \
+    do {                            \
+        int rc_ = (expr);           \
+        if (rc_ != FMRX_OK) return rc_; \
+    } while (0)
+
+// true when at least one HIP device is usable; otherwise sets the error and
+// the caller returns FMRX_ENODEV.  There is deliberately no CPU path.
+int require_device();
+
+// ---- small RAII device buffer ----------------------------------------------
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    int alloc(size_t count)
+    {
+        release();
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+        if (e != hipSuccess) return fail(FMRX_ENOMEM, "hipMalloc(%zu bytes): %s", count * sizeof(T), hipGetErrorString(e));
+        n = count;
+        return FMRX_OK;
+    }
+    int ensure(size_t count) { return count <= n ? FMRX_OK : alloc(count); }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+// ---- front-end fast path (kernels_fe.hip) -----------------------------------
+// Device-side tap table for the register-window FIR: phase-major, padded,
+// pre-scaled.  See kernels_fe.hip for the layout.
+struct FePlan {
+    int taps = 0, decim = 0;
+    bool fast = false;         // a specialised kernel exists for (taps, decim)
+    int hist_bytes = 0;        // bytes of u8 history the kernel reads before the block (multiple of 16)
+    DevBuf<float> table;       // fast-path table
+    DevBuf<float> h;           // plain taps (generic path)
+    float c0 = 0.0f;           // accumulator seed: -(sum of taps)
+};
+int fe_plan_init(FePlan &pl, const float *h, int taps, int decim);
+// d_hist: hist_bytes bytes whose LAST 2*(taps-1) hold the previous samples.
+// Writes n_samples/decim float2 (I,Q) to d_if.
+int fe_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist, float *d_if,
+              hipStream_t stream, bool force_generic);
+int fe_hist_bytes(int taps);
+
+// ---- audio fast path (kernels_audio.hip) --------------------------------------
+struct AudioPlan {
+    int taps = 0, decim = 0;
+    bool fast = false;
+    DevBuf<float> table;
+    DevBuf<float> h;
+};
+int audio_plan_init(AudioPlan &pl, const float *h, int taps, int decim);
+// y[k] = sum_n h[n] * x[decim*k - n - delay]; x points at the block start and
+// x[-(taps-1+delay) .. -1] must be readable history.
+int audio_fir_launch(const AudioPlan &pl, const float *d_x, size_t n_in, int delay, float *d_y, hipStream_t stream,
+                     bool force_generic);
+
+// ---- generic kernels (kernels_generic.hip) ----------------------------------
+// y[k] = sum_{n<taps} h[n]*x[decim*k - n], sequential mul+add in n (bit-compatible
+// with the reference's evaluation order).  x[-(taps-1)..-1] must be readable.
+int k_fir_generic(const float *d_x, size_t n_out, const float *d_h, int taps, int decim, float *d_y, hipStream_t s);
+// same on interleaved u8 I/Q with (u-128)/128 fused; writes float2 (I,Q)
+int k_fe_generic(const uint8_t *d_iq, const uint8_t *d_hist, int hist_bytes, size_t n_samples, const float *d_h,
+                 int taps, int decim, float *d_if, hipStream_t s);
+// polyphase resampler in stream form; d_x[-(hist)..-1] readable, hist=(taps-1)/upsamp
+int k_resample_generic(const float *d_x, size_t n_in, const float *d_h, int taps, int decim, int upsamp, float *d_y,
+                       hipStream_t s);
+// demod[k] from interleaved IF (I,Q); IF[-1] = *d_prev (float2). Also stores IF[n-1] to d_prev_out when non-null.
+int k_fm_demod_if(const float *d_if, size_t n, const float *d_prev, float *d_prev_out, float *d_demod, hipStream_t s);
+int k_fm_demod_planar(const float *d_i, const float *d_q, size_t n, float prev_i, float prev_q, float *d_demod,
+                      hipStream_t s);
+int k_u8_to_f32(const uint8_t *d_raw, size_t n, float *d_out, hipStream_t s);
+int k_deinterleave(const float *d_iq, size_t n_pairs, float *d_i, float *d_q, hipStream_t s);
+int k_split_if(const float *d_if, size_t n, float *d_i, float *d_q, hipStream_t s);
+int k_pcm16(const float *d_a, size_t n, int16_t *d_out, int wrap, hipStream_t s);
+int k_pcm16_stereo(const float *d_l, const float *d_r, size_t n, int16_t *d_out, int wrap, hipStream_t s);
+int k_all_pass(const float *d_in, size_t n, const float *d_state, size_t nstate, float *d_out, hipStream_t s);
+int k_fm_pll(const float *d_in, size_t n, float *d_out, float *d_state, float freq, float Fs, float ncoScale,
+             float phaseAdjust, float normBandwidth, hipStream_t s);
+int k_mix(const float *d_bpf, const float *d_pll, size_t n, float *d_mix, hipStream_t s);
+int k_combine(const float *d_st, const float *d_mono, size_t n, float *d_l, float *d_r, hipStream_t s);
+int k_upsample(const float *d_x, size_t n, float *d_xu, int up, hipStream_t s);
+int k_downsample(const float *d_in, size_t n_out, float *d_out, int ds, hipStream_t s);
+int k_fill_u8(uint8_t *d, size_t n, uint8_t v, hipStream_t s);
+
+// ---- host-side coefficient design (coeff.cpp) --------------------------------
+void design_lpf(float Fs, float Fc, int taps, float *h);
+void design_bpf(float Fs, float Fb, float Fe, int taps, float *h);
+
+}  // namespace fmrx

@@ -1,0 +1,162 @@
+// fmrx_project -- drop-in streaming receiver: raw u8 I/Q on stdin -> s16 PCM
+// on stdout, processing on the MI355X through libfmrx.so.
+//
+// Process contract of the reference (src/project.cpp:385-500 and
+// src/threadMonoOnly.cpp:206-267):
+//   fmrx_project                    mode 0, mono          (project.cpp:390-392)
+//   fmrx_project <mode> <channels>  mode 0..3, 1|2 chans  (project.cpp:393-412)
+//   fmrx_project <mode>             mono, like threadMonoOnly (:210-224)
+//   stdin : interleaved unsigned 8-bit I,Q            (src/iofunc.cpp:128-135)
+//   stdout: native-endian s16, sample*16384, mono, or L,R interleaved for
+//           2 channels (threadMonoOnly.cpp:185-191; project.cpp:292-302)
+//   a trailing partial block is dropped                (project.cpp:78-79, 83)
+//   diagnostics go to stderr; stdout carries PCM only.
+// Same structure as the reference: a producer thread reads blocks into a
+// bounded queue of QUEUE_ELEMS = 6 (include/dy4.h:30) while the consumer runs
+// the device pipeline and writes PCM -- so stdin I/O overlaps GPU work -- but
+// unlike the reference the queue is drained at EOF (its exit(1) in the producer
+// drops up to 7 blocks nondeterministically) and the exit status is
+// 0 unless --compat-exit asks for the reference's 1.
+// Extra options (all --flags, never positional):
+//   --rf-taps N --audio-taps N --stereo-taps N   (defaults 101 101 101)
+//   --blocks-per-call K   process K reference-size blocks per device call
+//   --saturate            clamp PCM instead of the reference's wrap-around
+//   --device N            HIP device ordinal
+//   --compat-exit         exit status 1 at EOF, like the reference
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <queue>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "fmrx.h"
+
+namespace {
+constexpr size_t kQueueElems = 6;
+
+struct BlockQueue {
+    std::queue<std::vector<uint8_t>> q;
+    std::mutex m;
+    std::condition_variable cv;
+    bool done = false;
+};
+
+[[noreturn]] void usage(const char *argv0)
+{
+    std::fprintf(stderr,
+                 "Usage: %s [<mode 0-3> [<channels 1-2>]] [--rf-taps N] [--audio-taps N] [--stereo-taps N]\n"
+                 "          [--blocks-per-call K] [--saturate] [--device N] [--compat-exit]\n",
+                 argv0);
+    std::exit(1);
+}
+}  // namespace
+
+int main(int argc, char *argv[])
+{
+    int mode = 0, channels = 1, rf_taps = 101, audio_taps = 101, stereo_taps = 101, device = 0, per_call = 1;
+    bool saturate = false, compat_exit = false;
+    std::vector<std::string> pos;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto next = [&](int &dst) {
+            if (i + 1 >= argc) usage(argv[0]);
+            dst = std::atoi(argv[++i]);
+        };
+        if (a == "--rf-taps") next(rf_taps);
+        else if (a == "--audio-taps") next(audio_taps);
+        else if (a == "--stereo-taps") next(stereo_taps);
+        else if (a == "--blocks-per-call") next(per_call);
+        else if (a == "--device") next(device);
+        else if (a == "--saturate") saturate = true;
+        else if (a == "--compat-exit") compat_exit = true;
+        else if (a.rfind("--", 0) == 0) usage(argv[0]);
+        else pos.push_back(a);
+    }
+    if (pos.size() > 2) usage(argv[0]);
+    if (!pos.empty()) mode = std::atoi(pos[0].c_str());
+    if (pos.size() == 2) channels = std::atoi(pos[1].c_str());
+    if (mode < 0 || mode > 3) {
+        std::fprintf(stderr, "Wrong mode %d\n", mode);
+        return 1;
+    }
+    if (channels < 1 || channels > 2) {
+        std::fprintf(stderr, "Wrong number of channels %d\n", channels);
+        return 1;
+    }
+    if (per_call < 1) per_call = 1;
+
+    fmrx_params p;
+    if (fmrx_mode_params(mode, rf_taps, audio_taps, stereo_taps, &p) != FMRX_OK) {
+        std::fprintf(stderr, "fmrx: %s\n", fmrx_last_error());
+        return 1;
+    }
+    const size_t block_bytes = static_cast<size_t>(p.block_bytes) * per_call;
+    std::fprintf(stderr, "Operating in mode:%d  Number of channels set to: %d  block_size = %zu  (%s)\n", mode, channels,
+                 block_bytes, fmrx_version());
+
+    fmrx_pipeline *pl = nullptr;
+    if (fmrx_pipeline_create(&pl, &p, channels, block_bytes, device) != FMRX_OK) {
+        std::fprintf(stderr, "fmrx: %s\n", fmrx_last_error());
+        return 2;
+    }
+
+    BlockQueue bq;
+    std::thread producer([&] {
+        for (;;) {
+            std::vector<uint8_t> blk(block_bytes);
+            const size_t got = std::fread(blk.data(), 1, block_bytes, stdin);
+            if (got != block_bytes) break;  // EOF: the partial block is ignored, as in the reference
+            std::unique_lock<std::mutex> lk(bq.m);
+            bq.cv.wait(lk, [&] { return bq.q.size() < kQueueElems; });
+            bq.q.push(std::move(blk));
+            bq.cv.notify_all();
+        }
+        std::lock_guard<std::mutex> lk(bq.m);
+        bq.done = true;
+        bq.cv.notify_all();
+    });
+
+    const size_t n_out = fmrx_pipeline_n_audio(pl, block_bytes) * channels;
+    std::vector<int16_t> pcm(n_out);
+    size_t blocks = 0;
+    int rc = 0;
+    for (;;) {
+        std::vector<uint8_t> blk;
+        {
+            std::unique_lock<std::mutex> lk(bq.m);
+            bq.cv.wait(lk, [&] { return !bq.q.empty() || bq.done; });
+            if (bq.q.empty()) break;
+            blk = std::move(bq.q.front());
+            bq.q.pop();
+            bq.cv.notify_all();
+        }
+        if (fmrx_pipeline_process(pl, blk.data(), blk.size(), nullptr, pcm.data(),
+                                  saturate ? FMRX_PCM_SATURATE : FMRX_PCM_WRAP) != FMRX_OK) {
+            std::fprintf(stderr, "fmrx: %s\n", fmrx_last_error());
+            rc = 3;
+            break;
+        }
+        if (std::fwrite(pcm.data(), sizeof(int16_t), pcm.size(), stdout) != pcm.size()) {
+            std::fprintf(stderr, "fmrx: short write on stdout\n");
+            rc = 4;
+            break;
+        }
+        blocks++;
+    }
+    if (rc != 0) {  // unblock and retire the producer
+        std::lock_guard<std::mutex> lk(bq.m);
+        while (!bq.q.empty()) bq.q.pop();
+        bq.cv.notify_all();
+        std::fclose(stdin);
+    }
+    producer.join();
+    std::fflush(stdout);
+    std::fprintf(stderr, "End of input stream reached after %zu blocks\n", blocks);
+    fmrx_pipeline_destroy(pl);
+    if (rc) return rc;
+    return compat_exit ? 1 : 0;
+}

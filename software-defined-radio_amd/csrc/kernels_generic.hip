@@ -1,0 +1,371 @@
+// kernels_generic.hip -- parameter-generic HIP kernels for every primitive of
+// the path (any tap count, any decimation, any alignment).
+//
+// These are the kernels behind the stage-level C ABI (one call per reference
+// primitive) and the fall-back of the pipeline when no specialised kernel
+// exists for a (taps, decim) pair.  They keep the reference's float32
+// evaluation ORDER (separate multiply and add, taps ascending, no FMA
+// contraction), so given identical inputs they reproduce the reference's
+// results bit for bit -- except fmPLL, whose sinf/cosf/atan2f come from the
+// device math library.  The throughput path is kernels_fe.hip /
+// kernels_audio.hip.
+//
+// Reference semantics: src/filter.cpp (line ranges cited per kernel).
+#include "fmrx_internal.hpp"
+
+// No implicit a*b+c -> fma anywhere in this file: the reference is built for
+// baseline x86-64 (no FMA), SURVEY A.2.
+#pragma clang fp contract(off)
+
+namespace fmrx {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+inline unsigned grid_for(size_t n, int per_block = kBlock)
+{
+    size_t g = (n + per_block - 1) / per_block;
+    return static_cast<unsigned>(g ? g : 1);
+}
+
+#define FMRX_LAUNCH_CHECK(name)                                                                   \
+    do {                                                                                          \
+        hipError_t e_ = hipGetLastError();                                                        \
+        if (e_ != hipSuccess) return fail(FMRX_EHIP, "launch %s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---- FIR, decimating, float in (src/filter.cpp:133-154, 158-188) ------------
+// One output per thread; x[-(taps-1)] .. x[-1] is the carried history.
+__global__ void fir_generic_kernel(const float *__restrict__ x, size_t n_out, const float *__restrict__ h, int taps,
+                                   int decim, float *__restrict__ y)
+{
+    const size_t k = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k >= n_out) return;
+    const float *xs = x + static_cast<ptrdiff_t>(k) * decim;
+    float acc = 0.0f;
+    for (int n = 0; n < taps; n++) {
+        const float prod = h[n] * xs[-n];
+        acc = acc + prod;
+    }
+    y[k] = acc;
+}
+
+// ---- front end on raw u8 I/Q (src/iofunc.cpp:133, project.cpp:98-121) ---------
+__device__ inline float u8_norm(uint8_t u)
+{
+    // (u-128)/128.0 in double then float: exact, so a float divide by 128 is identical
+    return static_cast<float>(static_cast<int>(u) - 128) * 0.0078125f;
+}
+
+__global__ void fe_generic_kernel(const uint8_t *__restrict__ iq, const uint8_t *__restrict__ hist, int hist_bytes,
+                                  size_t n_out, const float *__restrict__ h, int taps, int decim,
+                                  float2 *__restrict__ y)
+{
+    const size_t k = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k >= n_out) return;
+    const ptrdiff_t s0 = static_cast<ptrdiff_t>(k) * decim;  // complex-sample index of tap 0
+    float ai = 0.0f, aq = 0.0f;
+    for (int n = 0; n < taps; n++) {
+        const ptrdiff_t s = s0 - n;
+        uint8_t ui, uq;
+        if (s >= 0) {
+            ui = iq[2 * s];
+            uq = iq[2 * s + 1];
+        } else if (hist) {
+            ui = hist[hist_bytes + 2 * s];
+            uq = hist[hist_bytes + 2 * s + 1];
+        } else {
+            ui = uq = 128;
+        }
+        const float pi = h[n] * u8_norm(ui);
+        const float pq = h[n] * u8_norm(uq);
+        ai = ai + pi;
+        aq = aq + pq;
+    }
+    y[k] = make_float2(ai, aq);
+}
+
+// ---- polyphase rational resampler, stream form (src/filter.cpp:191-223) ---------
+// y[k] = (1+U) * sum_j h[ph + j*U] * x[(k*D - ph)/U - j],  ph = (k*D) % U
+__global__ void resample_generic_kernel(const float *__restrict__ x, size_t n_out, const float *__restrict__ h,
+                                        int taps, int decim, int upsamp, float *__restrict__ y)
+{
+    const size_t k = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k >= n_out) return;
+    const long long m = static_cast<long long>(k) * decim;
+    const int ph = static_cast<int>(m % upsamp);
+    const float *xs = x + (m - ph) / upsamp;
+    float acc = 0.0f;
+    int j = 0;
+    for (int n = ph; n < taps; n += upsamp, j++) {
+        const float prod = h[n] * xs[-j];
+        acc = acc + prod;
+    }
+    const float g = acc * static_cast<float>(upsamp);
+    y[k] = acc + g;
+}
+
+// ---- FM discriminator (src/filter.cpp:248-266) ------------------------------------
+__device__ inline float demod_one(float i, float q, float pi, float pq)
+{
+    const float ii = i * i, qq = q * q;
+    const float den = ii + qq;
+    if (den == 0.0f) return 0.0f;
+    const float a = i * (q - pq);
+    const float b = q * (i - pi);
+    return (a - b) / den;  // IEEE divide (no fast-math)
+}
+
+__global__ void demod_if_kernel(const float2 *__restrict__ z, size_t n, const float2 *__restrict__ prev,
+                                float2 *__restrict__ prev_out, float *__restrict__ out)
+{
+    const size_t k = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float2 c = z[k];
+    const float2 p = k ? z[k - 1] : *prev;
+    out[k] = demod_one(c.x, c.y, p.x, p.y);
+    if (prev_out && k == n - 1) *prev_out = c;
+}
+
+__global__ void demod_planar_kernel(const float *__restrict__ I, const float *__restrict__ Q, size_t n, float prev_i,
+                                    float prev_q, float *__restrict__ out)
+{
+    const size_t k = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float pi = k ? I[k - 1] : prev_i, pq = k ? Q[k - 1] : prev_q;
+    out[k] = demod_one(I[k], Q[k], pi, pq);
+}
+
+// ---- element-wise helpers ------------------------------------------------------------
+__global__ void u8_to_f32_kernel(const uint8_t *__restrict__ raw, size_t n, float *__restrict__ out)
+{
+    const size_t k = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = u8_norm(raw[k]);
+}
+
+__global__ void deinterleave_kernel(const float2 *__restrict__ iq, size_t n, float *__restrict__ I, float *__restrict__ Q)
+{
+    const size_t k = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k < n) {
+        const float2 v = iq[k];
+        I[k] = v.x;
+        Q[k] = v.y;
+    }
+}
+
+// src/threadMonoOnly.cpp:185-191
+__device__ inline int16_t pcm_one(float a, int wrap)
+{
+    if (a != a) return 0;
+    const float s = a * 16384;
+    if (wrap) {
+        // x86 cvttss2si: out-of-range -> 0x80000000, then the low 16 bits
+        int v;
+        if (s >= 2147483648.0f || s < -2147483648.0f) v = static_cast<int>(0x80000000u);
+        else v = static_cast<int>(s);
+        return static_cast<int16_t>(static_cast<uint16_t>(static_cast<uint32_t>(v)));
+    }
+    if (s >= 32767.0f) return 32767;
+    if (s <= -32768.0f) return -32768;
+    return static_cast<int16_t>(s);
+}
+
+__global__ void pcm16_kernel(const float *__restrict__ a, size_t n, int16_t *__restrict__ out, int wrap)
+{
+    const size_t k = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = pcm_one(a[k], wrap);
+}
+
+// interleaved L,R: the layout of the writer at src/project.cpp:292-302
+__global__ void pcm16_stereo_kernel(const float *__restrict__ l, const float *__restrict__ r, size_t n,
+                                    int16_t *__restrict__ out, int wrap)
+{
+    const size_t k = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k < n) {
+        out[2 * k] = pcm_one(l[k], wrap);
+        out[2 * k + 1] = pcm_one(r[k], wrap);
+    }
+}
+
+// src/filter.cpp:14-29: out = [state, in[0 .. n-ns)]
+__global__ void all_pass_kernel(const float *__restrict__ in, size_t n, const float *__restrict__ state, size_t ns,
+                                float *__restrict__ out)
+{
+    const size_t k = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = k < ns ? state[k] : in[k - ns];
+}
+
+// src/project.cpp:246-248: mixer = bpf * pll * 2
+__global__ void mix_kernel(const float *__restrict__ bpf, const float *__restrict__ pll, size_t n, float *__restrict__ out)
+{
+    const size_t k = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k < n) {
+        const float t = bpf[k] * pll[k];
+        out[k] = t * 2;
+    }
+}
+
+// src/project.cpp:277-280
+__global__ void combine_kernel(const float *__restrict__ st, const float *__restrict__ mono, size_t n,
+                               float *__restrict__ l, float *__restrict__ r)
+{
+    const size_t k = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k < n) {
+        l[k] = st[k] + mono[k];
+        r[k] = mono[k] - st[k];
+    }
+}
+
+// src/filter.cpp:227-245
+__global__ void upsample_kernel(const float *__restrict__ x, size_t n_out, float *__restrict__ xu, int up)
+{
+    const size_t k = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k < n_out) xu[k] = (k % up) == 0 ? x[k / up] : 0.0f;
+}
+
+__global__ void downsample_kernel(const float *__restrict__ in, size_t n_out, float *__restrict__ out, int ds)
+{
+    const size_t k = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k < n_out) out[k] = in[k * ds];
+}
+
+__global__ void fill_u8_kernel(uint8_t *d, size_t n, uint8_t v)
+{
+    const size_t k = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k < n) d[k] = v;
+}
+
+// ---- PLL / NCO (src/filter.cpp:32-80) ---------------------------------------------------
+// A serial float32 recurrence per channel: one lane walks the block.  state[6] =
+// {integrator, phaseEst, feedbackI, feedbackQ, lastOut, trigOffset}; out has n+1.
+__global__ void pll_kernel(const float *__restrict__ in, size_t n, float *__restrict__ out, float *__restrict__ state,
+                           float freq, float Fs, float ncoScale, float phaseAdjust, float normBandwidth)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const float Cp = 2.666f, Ci = 3.555f;
+    const float Kp = normBandwidth * Cp;
+    const float Ki = (normBandwidth * normBandwidth) * Ci;
+    float integrator = state[0], phaseEst = state[1], fbI = state[2], fbQ = state[3];
+    float trigOffset = state[5];
+    out[0] = state[4];
+    const double w = 2 * 3.14159265358979323846 * static_cast<double>(freq / Fs);
+    float last = state[4];
+    for (size_t k = 0; k < n; k++) {
+        const float v = in[k];
+        const float eI = v * fbI;
+        const float eQ = v * (-1 * fbQ);
+        const float eD = atan2f(eQ, eI);
+        integrator = integrator + Ki * eD;
+        const float pe = Kp * eD;
+        phaseEst = (phaseEst + pe) + integrator;
+        trigOffset += 1;
+        const float trigArg = static_cast<float>(w * static_cast<double>(trigOffset) + static_cast<double>(phaseEst));
+        fbI = cosf(trigArg);
+        fbQ = sinf(trigArg);
+        const float sc = trigArg * ncoScale;
+        last = cosf(sc + phaseAdjust);
+        out[k + 1] = last;
+    }
+    state[0] = integrator;
+    state[1] = phaseEst;
+    state[2] = fbI;
+    state[3] = fbQ;
+    state[4] = last;
+    state[5] = trigOffset;
+}
+
+}  // namespace
+
+int k_fir_generic(const float *d_x, size_t n_out, const float *d_h, int taps, int decim, float *d_y, hipStream_t s)
+{
+    if (n_out == 0) return FMRX_OK;
+    hipLaunchKernelGGL(fir_generic_kernel, dim3(grid_for(n_out)), dim3(kBlock), 0, s, d_x, n_out, d_h, taps, decim, d_y);
+    FMRX_LAUNCH_CHECK("fir_generic");
+    return FMRX_OK;
+}
+
+int k_fe_generic(const uint8_t *d_iq, const uint8_t *d_hist, int hist_bytes, size_t n_samples, const float *d_h,
+                 int taps, int decim, float *d_if, hipStream_t s)
+{
+    const size_t n_out = n_samples / decim;
+    if (n_out == 0) return FMRX_OK;
+    hipLaunchKernelGGL(fe_generic_kernel, dim3(grid_for(n_out)), dim3(kBlock), 0, s, d_iq, d_hist, hist_bytes, n_out,
+                       d_h, taps, decim, reinterpret_cast<float2 *>(d_if));
+    FMRX_LAUNCH_CHECK("fe_generic");
+    return FMRX_OK;
+}
+
+int k_resample_generic(const float *d_x, size_t n_in, const float *d_h, int taps, int decim, int upsamp, float *d_y,
+                       hipStream_t s)
+{
+    const size_t n_out = (n_in * static_cast<size_t>(upsamp)) / decim;
+    if (n_out == 0) return FMRX_OK;
+    hipLaunchKernelGGL(resample_generic_kernel, dim3(grid_for(n_out)), dim3(kBlock), 0, s, d_x, n_out, d_h, taps, decim,
+                       upsamp, d_y);
+    FMRX_LAUNCH_CHECK("resample_generic");
+    return FMRX_OK;
+}
+
+int k_fm_demod_if(const float *d_if, size_t n, const float *d_prev, float *d_prev_out, float *d_demod, hipStream_t s)
+{
+    if (n == 0) return FMRX_OK;
+    hipLaunchKernelGGL(demod_if_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, reinterpret_cast<const float2 *>(d_if), n,
+                       reinterpret_cast<const float2 *>(d_prev), reinterpret_cast<float2 *>(d_prev_out), d_demod);
+    FMRX_LAUNCH_CHECK("demod_if");
+    return FMRX_OK;
+}
+
+int k_fm_demod_planar(const float *d_i, const float *d_q, size_t n, float prev_i, float prev_q, float *d_demod,
+                      hipStream_t s)
+{
+    if (n == 0) return FMRX_OK;
+    hipLaunchKernelGGL(demod_planar_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, d_i, d_q, n, prev_i, prev_q, d_demod);
+    FMRX_LAUNCH_CHECK("demod_planar");
+    return FMRX_OK;
+}
+
+#define FMRX_ELEMENTWISE(fn, kern, n, ...)                                                     \
+    int fn                                                                                     \
+    {                                                                                          \
+        if ((n) == 0) return FMRX_OK;                                                          \
+        hipLaunchKernelGGL(kern, dim3(grid_for(n)), dim3(kBlock), 0, s, __VA_ARGS__);          \
+        FMRX_LAUNCH_CHECK(#kern);                                                              \
+        return FMRX_OK;                                                                        \
+    }
+
+FMRX_ELEMENTWISE(k_u8_to_f32(const uint8_t *d_raw, size_t n, float *d_out, hipStream_t s), u8_to_f32_kernel, n, d_raw, n, d_out)
+FMRX_ELEMENTWISE(k_deinterleave(const float *d_iq, size_t n, float *d_i, float *d_q, hipStream_t s), deinterleave_kernel, n,
+                 reinterpret_cast<const float2 *>(d_iq), n, d_i, d_q)
+FMRX_ELEMENTWISE(k_pcm16(const float *d_a, size_t n, int16_t *d_out, int wrap, hipStream_t s), pcm16_kernel, n, d_a, n, d_out, wrap)
+FMRX_ELEMENTWISE(k_pcm16_stereo(const float *d_l, const float *d_r, size_t n, int16_t *d_out, int wrap, hipStream_t s),
+                 pcm16_stereo_kernel, n, d_l, d_r, n, d_out, wrap)
+FMRX_ELEMENTWISE(k_all_pass(const float *d_in, size_t n, const float *d_state, size_t nstate, float *d_out, hipStream_t s),
+                 all_pass_kernel, n, d_in, n, d_state, nstate, d_out)
+FMRX_ELEMENTWISE(k_mix(const float *d_bpf, const float *d_pll, size_t n, float *d_mix, hipStream_t s), mix_kernel, n, d_bpf, d_pll, n, d_mix)
+FMRX_ELEMENTWISE(k_combine(const float *d_st, const float *d_mono, size_t n, float *d_l, float *d_r, hipStream_t s),
+                 combine_kernel, n, d_st, d_mono, n, d_l, d_r)
+FMRX_ELEMENTWISE(k_downsample(const float *d_in, size_t n, float *d_out, int ds, hipStream_t s), downsample_kernel, n, d_in, n, d_out, ds)
+FMRX_ELEMENTWISE(k_fill_u8(uint8_t *d, size_t n, uint8_t v, hipStream_t s), fill_u8_kernel, n, d, n, v)
+
+int k_split_if(const float *d_if, size_t n, float *d_i, float *d_q, hipStream_t s) { return k_deinterleave(d_if, n, d_i, d_q, s); }
+
+int k_upsample(const float *d_x, size_t n, float *d_xu, int up, hipStream_t s)
+{
+    const size_t n_out = n * static_cast<size_t>(up);
+    if (n_out == 0) return FMRX_OK;
+    hipLaunchKernelGGL(upsample_kernel, dim3(grid_for(n_out)), dim3(kBlock), 0, s, d_x, n_out, d_xu, up);
+    FMRX_LAUNCH_CHECK("upsample");
+    return FMRX_OK;
+}
+
+int k_fm_pll(const float *d_in, size_t n, float *d_out, float *d_state, float freq, float Fs, float ncoScale,
+             float phaseAdjust, float normBandwidth, hipStream_t s)
+{
+    hipLaunchKernelGGL(pll_kernel, dim3(1), dim3(64), 0, s, d_in, n, d_out, d_state, freq, Fs, ncoScale, phaseAdjust,
+                       normBandwidth);
+    FMRX_LAUNCH_CHECK("pll");
+    return FMRX_OK;
+}
+
+}  // namespace fmrx

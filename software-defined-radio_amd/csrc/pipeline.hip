@@ -1,0 +1,502 @@
+// pipeline.hip -- the receiver pipeline handle of include/fmrx.h.
+//
+// Replaces main()'s setup and the three thread bodies of the reference:
+//   RF_FrontEnd  src/project.cpp:40-152   (u8 -> IF I/Q -> FM demod)
+//   RF_MONO      src/project.cpp:311-382  (audio FIR + decimate | resample)
+//   RF_STEREO    src/project.cpp:154-309  (all-pass, pilot/stereo BPFs, PLL,
+//                                          mixer, second audio FIR, L/R)
+// with every intermediate resident in HBM and the carried state
+// (src/project.cpp:61-65, 446-458) owned by the handle.  The producer/consumer
+// queue of the reference (project.cpp:470-496) has no counterpart here: stages
+// are kernels on one HIP stream, so the hand-off is stream order.
+//
+// Device layout of one block (n = complex input samples, n_if = n/rf_decim):
+//   in      u8   [hist_bytes | 2n]            raw I/Q, FE history in front
+//   ifb     f32  [2 n_if]                     interleaved IF I,Q
+//   demod   f32  [Hd | n_if]                  discriminator output, history in front
+//   mono    f32  [n_audio]
+//   stereo: carrier, bpf [n_if]; pll [n_if+1]; mixer [Ha | n_if]; final, L, R [n_audio]
+// The all-pass delay of the stereo path (project.cpp:194, filter.cpp:14-29) is
+// not a kernel: the mono audio FIR simply reads demod `delay` samples earlier.
+#include "fmrx_internal.hpp"
+
+using namespace fmrx;
+
+struct fmrx_pipeline {
+    fmrx_params p{};
+    int channels = 1;
+    int device = 0;
+    size_t max_bytes = 0;
+    bool resample = false;
+    bool force_generic = false;
+    bool profiling = false;
+    int Ha = 0;     // audio-stage history, in its input samples
+    int delay = 0;  // all-pass delay (stereo), samples
+    int Hd = 0;     // history kept in front of demod
+    int St = 0;     // stereo taps
+
+    hipStream_t stream = nullptr;  // used by the host-buffer entry point
+    FePlan fe;
+    AudioPlan audio;
+    DevBuf<float> h_audio_rs;  // resampler taps (modes 2, 3)
+    DevBuf<float> h_carrier, h_stereo;
+
+    DevBuf<uint8_t> in;
+    DevBuf<uint8_t> fe_hist[2];
+    int fe_cur = 0;
+    DevBuf<float> prev_iq[2];
+    int prev_cur = 0;
+    DevBuf<float> ifb, demod, mono, tmp_hist;
+    DevBuf<float> carrier, bpf, pll, pll_state, mixer, st_final, left, right;
+    DevBuf<float> out_f32;
+    DevBuf<int16_t> out_pcm;
+
+    size_t last_n_if = 0, last_n_audio = 0;
+    // profiling: a ring of per-call event quadruples {start, after FE kernel,
+    // after audio stage, end}, recorded on the caller's stream
+    static constexpr int kRing = 128;
+    hipEvent_t ev[kRing][4] = {};
+    unsigned long calls = 0;      // profiled calls since profiling was enabled
+};
+
+namespace {
+
+__global__ void hist_update_kernel(const uint8_t *__restrict__ old_hist, const uint8_t *__restrict__ x, long n_bytes,
+                                   int hb, uint8_t *__restrict__ new_hist)
+{
+    // new history = last hb bytes of the stream [old_hist | x]
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hb) return;
+    const long src = static_cast<long>(i) + n_bytes - hb;  // offset into x; negative -> old history
+    new_hist[i] = src >= 0 ? x[src] : old_hist[hb + src];
+}
+
+int n_if_of(const fmrx_pipeline *pl, size_t n_bytes) { return static_cast<int>((n_bytes / 2) / pl->p.rf_decim); }
+
+size_t n_audio_of(const fmrx_pipeline *pl, size_t n_bytes)
+{
+    const size_t n_if = (n_bytes / 2) / pl->p.rf_decim;
+    if (pl->resample) return (n_if * static_cast<size_t>(pl->p.audio_upsamp)) / pl->p.audio_decim;
+    return n_if / pl->p.audio_decim;
+}
+
+// keep the last `keep` floats of [hist | block] in front for the next block
+int carry_history(fmrx_pipeline *pl, float *buf, int keep, size_t n_block, hipStream_t s)
+{
+    if (keep == 0) return FMRX_OK;
+    // source = buf[n_block .. n_block+keep) ; may overlap the destination when n_block < keep
+    FMRX_HIP(hipMemcpyAsync(pl->tmp_hist.p, buf + n_block, keep * sizeof(float), hipMemcpyDeviceToDevice, s));
+    FMRX_HIP(hipMemcpyAsync(buf, pl->tmp_hist.p, keep * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return FMRX_OK;
+}
+
+int audio_stage(fmrx_pipeline *pl, const float *d_x, size_t n_in, int delay, float *d_y, hipStream_t s)
+{
+    if (pl->resample)
+        return k_resample_generic(d_x - delay, n_in, pl->h_audio_rs.p, pl->p.audio_taps, pl->p.audio_decim,
+                                  pl->p.audio_upsamp, d_y, s);
+    return audio_fir_launch(pl->audio, d_x, n_in, delay, d_y, s, pl->force_generic);
+}
+
+int reset_state(fmrx_pipeline *pl)
+{
+    hipStream_t s = pl->stream;
+    for (int i = 0; i < 2; i++) {
+        FMRX_TRY(k_fill_u8(pl->fe_hist[i].p, pl->fe.hist_bytes, 128, s));
+        FMRX_HIP(hipMemsetAsync(pl->prev_iq[i].p, 0, 2 * sizeof(float), s));
+    }
+    FMRX_HIP(hipMemsetAsync(pl->demod.p, 0, pl->Hd * sizeof(float), s));
+    if (pl->channels == 2) {
+        FMRX_HIP(hipMemsetAsync(pl->mixer.p, 0, pl->Ha * sizeof(float), s));
+        const float init[6] = {0.0f, 0.0f, 1.0f, 0.0f, 1.0f, 0.0f};  // src/project.cpp:458
+        FMRX_HIP(hipMemcpyAsync(pl->pll_state.p, init, sizeof(init), hipMemcpyHostToDevice, s));
+    }
+    FMRX_HIP(hipStreamSynchronize(s));
+    pl->fe_cur = pl->prev_cur = 0;
+    return FMRX_OK;
+}
+
+int check_block(const fmrx_pipeline *pl, size_t n_bytes)
+{
+    const fmrx_params &p = pl->p;
+    if (n_bytes == 0 || n_bytes % 2) return fail(FMRX_EINVAL, "process: n_bytes %zu must be a positive even number", n_bytes);
+    if (n_bytes > pl->max_bytes) return fail(FMRX_EINVAL, "process: block of %zu bytes exceeds max_block_bytes %zu", n_bytes, pl->max_bytes);
+    const size_t n = n_bytes / 2;
+    if (n % p.rf_decim) return fail(FMRX_EINVAL, "process: %zu samples not a multiple of rf_decim %d", n, p.rf_decim);
+    if (n < static_cast<size_t>(p.rf_taps - 1)) return fail(FMRX_EINVAL, "process: %zu samples < rf_taps-1", n);
+    const size_t n_if = n / p.rf_decim;
+    if (pl->resample) {
+        if ((n_if * p.audio_upsamp) % p.audio_decim)
+            return fail(FMRX_EINVAL, "process: n_if*upsamp = %zu not a multiple of audio_decim %d", n_if * p.audio_upsamp, p.audio_decim);
+    } else if (n_if % p.audio_decim) {
+        return fail(FMRX_EINVAL, "process: %zu IF samples not a multiple of audio_decim %d", n_if, p.audio_decim);
+    }
+    if (n_if < static_cast<size_t>(pl->Ha)) return fail(FMRX_EINVAL, "process: %zu IF samples < audio history %d", n_if, pl->Ha);
+    if (pl->channels == 2 && n_if < static_cast<size_t>(pl->St - 1))
+        return fail(FMRX_EINVAL, "process: %zu IF samples < stereo_taps-1", n_if);
+    return FMRX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fmrx_pipeline_create(fmrx_pipeline **out, const fmrx_params *p, int channels, size_t max_block_bytes, int device)
+{
+    if (!out || !p) return fail(FMRX_EINVAL, "pipeline_create: null argument");
+    if (channels != 1 && channels != 2) return fail(FMRX_EINVAL, "pipeline_create: channels must be 1 or 2");
+    if (p->rf_taps < 2 || p->rf_taps > 65535 || p->audio_taps < 2 || p->audio_taps > 65535 || p->rf_decim < 1 ||
+        p->audio_decim < 1 || p->audio_upsamp < 0)
+        return fail(FMRX_EINVAL, "pipeline_create: bad parameters");
+    if (channels == 2 && (p->stereo_taps < 2 || p->stereo_taps > 65535))
+        return fail(FMRX_EINVAL, "pipeline_create: bad stereo_taps");
+    if (max_block_bytes < 2) return fail(FMRX_EINVAL, "pipeline_create: max_block_bytes too small");
+    FMRX_TRY(require_device());
+    FMRX_HIP(hipSetDevice(device));
+
+    fmrx_pipeline *pl = new fmrx_pipeline;
+    pl->p = *p;
+    pl->channels = channels;
+    pl->device = device;
+    pl->max_bytes = max_block_bytes;
+    pl->resample = p->audio_upsamp > 0;
+    pl->Ha = pl->resample ? (p->audio_taps - 1) / p->audio_upsamp : p->audio_taps - 1;
+    pl->St = channels == 2 ? p->stereo_taps : 0;
+    pl->delay = channels == 2 ? (p->stereo_taps - 1) / 2 : 0;
+    pl->Hd = pl->Ha + pl->delay;
+    if (channels == 2 && pl->St - 1 > pl->Hd) pl->Hd = pl->St - 1;
+
+    int rc = FMRX_OK;
+    auto body = [&]() -> int {
+        FMRX_HIP(hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking));
+        for (auto &q : pl->ev)
+            for (auto &e : q) FMRX_HIP(hipEventCreate(&e));
+        // coefficients: project.cpp:50 (rf), :321-323 (audio), :172-173 (stereo)
+        std::vector<float> h(p->rf_taps);
+        design_lpf(static_cast<float>(p->rf_Fs), static_cast<float>(100000), p->rf_taps, h.data());
+        FMRX_TRY(fe_plan_init(pl->fe, h.data(), p->rf_taps, p->rf_decim));
+        h.resize(p->audio_taps);
+        const int design_fs = pl->resample ? p->if_Fs * p->audio_upsamp : p->if_Fs;
+        design_lpf(static_cast<float>(design_fs), static_cast<float>(16000), p->audio_taps, h.data());
+        if (pl->resample) {
+            FMRX_TRY(pl->h_audio_rs.alloc(p->audio_taps));
+            FMRX_HIP(hipMemcpy(pl->h_audio_rs.p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+        } else {
+            FMRX_TRY(audio_plan_init(pl->audio, h.data(), p->audio_taps, p->audio_decim));
+        }
+        const size_t n_max = max_block_bytes / 2;
+        const size_t n_if = n_max / p->rf_decim;
+        const size_t n_au = n_audio_of(pl, max_block_bytes) + 1;
+        FMRX_TRY(pl->in.alloc(pl->fe.hist_bytes + max_block_bytes + 16));
+        for (int i = 0; i < 2; i++) {
+            FMRX_TRY(pl->fe_hist[i].alloc(pl->fe.hist_bytes));
+            FMRX_TRY(pl->prev_iq[i].alloc(2));
+        }
+        FMRX_TRY(pl->ifb.alloc(2 * n_if + 16));
+        FMRX_TRY(pl->demod.alloc(pl->Hd + n_if + 16));
+        FMRX_TRY(pl->tmp_hist.alloc(pl->Hd + pl->Ha + 16));
+        FMRX_TRY(pl->mono.alloc(n_au));
+        if (channels == 2) {
+            h.resize(p->stereo_taps);
+            design_bpf(static_cast<float>(p->if_Fs), 18.5e3f, 19.5e3f, p->stereo_taps, h.data());
+            FMRX_TRY(pl->h_carrier.alloc(p->stereo_taps));
+            FMRX_HIP(hipMemcpy(pl->h_carrier.p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+            design_bpf(static_cast<float>(p->if_Fs), 22e3f, 54e3f, p->stereo_taps, h.data());
+            FMRX_TRY(pl->h_stereo.alloc(p->stereo_taps));
+            FMRX_HIP(hipMemcpy(pl->h_stereo.p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+            FMRX_TRY(pl->carrier.alloc(n_if + 16));
+            FMRX_TRY(pl->bpf.alloc(n_if + 16));
+            FMRX_TRY(pl->pll.alloc(n_if + 17));
+            FMRX_TRY(pl->pll_state.alloc(8));
+            FMRX_TRY(pl->mixer.alloc(pl->Ha + n_if + 16));
+            FMRX_TRY(pl->st_final.alloc(n_au));
+            FMRX_TRY(pl->left.alloc(n_au));
+            FMRX_TRY(pl->right.alloc(n_au));
+        }
+        FMRX_TRY(pl->out_f32.alloc(2 * n_au));
+        FMRX_TRY(pl->out_pcm.alloc(2 * n_au));
+        return reset_state(pl);
+    };
+    rc = body();
+    if (rc != FMRX_OK) {
+        fmrx_pipeline_destroy(pl);
+        return rc;
+    }
+    *out = pl;
+    return FMRX_OK;
+}
+
+int fmrx_pipeline_destroy(fmrx_pipeline *pl)
+{
+    if (!pl) return FMRX_OK;
+    (void)hipSetDevice(pl->device);
+    if (pl->stream) {
+        (void)hipStreamSynchronize(pl->stream);
+        (void)hipStreamDestroy(pl->stream);
+    }
+    for (auto &q : pl->ev)
+        for (auto &e : q)
+            if (e) (void)hipEventDestroy(e);
+    delete pl;
+    return FMRX_OK;
+}
+
+int fmrx_pipeline_reset(fmrx_pipeline *pl)
+{
+    if (!pl) return fail(FMRX_EINVAL, "pipeline_reset: null handle");
+    FMRX_HIP(hipSetDevice(pl->device));
+    return reset_state(pl);
+}
+
+size_t fmrx_pipeline_n_if(const fmrx_pipeline *pl, size_t n_bytes) { return pl ? n_if_of(pl, n_bytes) : 0; }
+size_t fmrx_pipeline_n_audio(const fmrx_pipeline *pl, size_t n_bytes) { return pl ? n_audio_of(pl, n_bytes) : 0; }
+
+int fmrx_pipeline_set_profiling(fmrx_pipeline *pl, int on)
+{
+    if (!pl) return fail(FMRX_EINVAL, "null handle");
+    pl->profiling = on != 0;
+    pl->calls = 0;
+    return FMRX_OK;
+}
+
+int fmrx_pipeline_set_force_generic(fmrx_pipeline *pl, int on)
+{
+    if (!pl) return fail(FMRX_EINVAL, "null handle");
+    pl->force_generic = on != 0;
+    return FMRX_OK;
+}
+
+int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_bytes, float *d_audio_f32,
+                              int16_t *d_pcm16, int pcm_policy, void *stream)
+{
+    if (!pl || !d_iq) return fail(FMRX_EINVAL, "process_dev: null argument");
+    FMRX_TRY(check_block(pl, n_bytes));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const fmrx_params &p = pl->p;
+    const size_t n = n_bytes / 2;
+    const size_t n_if = n / p.rf_decim;
+    const size_t n_au = n_audio_of(pl, n_bytes);
+    pl->last_n_if = n_if;
+    pl->last_n_audio = n_au;
+    float *demod = pl->demod.p + pl->Hd;
+
+    hipEvent_t *ev = pl->ev[pl->calls % fmrx_pipeline::kRing];
+    if (pl->profiling) FMRX_HIP(hipEventRecord(ev[0], s));
+
+    // ---- RF_FrontEnd: project.cpp:82-128 ----
+    const uint8_t *hist = pl->fe_hist[pl->fe_cur].p;
+    FMRX_TRY(fe_launch(pl->fe, d_iq, n, hist, pl->ifb.p, s, pl->force_generic));
+    if (pl->profiling) FMRX_HIP(hipEventRecord(ev[1], s));
+    {   // I_state/Q_state <- last rf_taps-1 samples (filter.cpp:182-187), as raw bytes
+        const int hb = pl->fe.hist_bytes;
+        hipLaunchKernelGGL(hist_update_kernel, dim3((hb + 255) / 256), dim3(256), 0, s, hist, d_iq,
+                           static_cast<long>(n_bytes), hb, pl->fe_hist[pl->fe_cur ^ 1].p);
+        pl->fe_cur ^= 1;
+    }
+    FMRX_TRY(k_fm_demod_if(pl->ifb.p, n_if, pl->prev_iq[pl->prev_cur].p, pl->prev_iq[pl->prev_cur ^ 1].p, demod, s));
+    pl->prev_cur ^= 1;
+
+    float *out_l = pl->mono.p, *out_r = nullptr;
+    if (pl->channels == 1) {
+        // ---- RF_MONO: project.cpp:344-357 ----
+        FMRX_TRY(audio_stage(pl, demod, n_if, 0, pl->mono.p, s));
+        if (pl->profiling) FMRX_HIP(hipEventRecord(ev[2], s));
+    } else {
+        // ---- RF_STEREO: project.cpp:194-280 ----
+        float *mixer = pl->mixer.p + pl->Ha;
+        FMRX_TRY(audio_stage(pl, demod, n_if, pl->delay, pl->mono.p, s));  // all-pass = index offset
+        if (pl->profiling) FMRX_HIP(hipEventRecord(ev[2], s));
+        FMRX_TRY(k_fir_generic(demod, n_if, pl->h_stereo.p, pl->St, 1, pl->bpf.p, s));
+        FMRX_TRY(k_fir_generic(demod, n_if, pl->h_carrier.p, pl->St, 1, pl->carrier.p, s));
+        FMRX_TRY(k_fm_pll(pl->carrier.p, n_if, pl->pll.p, pl->pll_state.p, 19e3f, static_cast<float>(p.if_Fs), 2.0f,
+                          0.0f, 0.01f, s));
+        FMRX_TRY(k_mix(pl->bpf.p, pl->pll.p, n_if, mixer, s));
+        FMRX_TRY(audio_stage(pl, mixer, n_if, 0, pl->st_final.p, s));
+        FMRX_TRY(k_combine(pl->st_final.p, pl->mono.p, n_au, pl->left.p, pl->right.p, s));
+        FMRX_TRY(carry_history(pl, pl->mixer.p, pl->Ha, n_if, s));
+        out_l = pl->left.p;
+        out_r = pl->right.p;
+    }
+    FMRX_TRY(carry_history(pl, pl->demod.p, pl->Hd, n_if, s));
+
+    // ---- outputs ----
+    if (d_audio_f32) {
+        FMRX_HIP(hipMemcpyAsync(d_audio_f32, out_l, n_au * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (out_r) FMRX_HIP(hipMemcpyAsync(d_audio_f32 + n_au, out_r, n_au * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    if (d_pcm16) {
+        if (out_r) FMRX_TRY(k_pcm16_stereo(out_l, out_r, n_au, d_pcm16, pcm_policy, s));
+        else FMRX_TRY(k_pcm16(out_l, n_au, d_pcm16, pcm_policy, s));
+    }
+    if (pl->profiling) {
+        FMRX_HIP(hipEventRecord(ev[3], s));
+        pl->calls++;
+    }
+    return FMRX_OK;
+}
+
+int fmrx_pipeline_process(fmrx_pipeline *pl, const uint8_t *iq, size_t n_bytes, float *audio_f32, int16_t *pcm16,
+                          int pcm_policy)
+{
+    if (!pl || !iq) return fail(FMRX_EINVAL, "process: null argument");
+    FMRX_TRY(check_block(pl, n_bytes));
+    FMRX_HIP(hipSetDevice(pl->device));
+    hipStream_t s = pl->stream;
+    const size_t n_au = n_audio_of(pl, n_bytes);
+    const size_t nch = pl->channels;
+    FMRX_HIP(hipMemcpyAsync(pl->in.p, iq, n_bytes, hipMemcpyHostToDevice, s));
+    FMRX_TRY(fmrx_pipeline_process_dev(pl, pl->in.p, n_bytes, audio_f32 ? pl->out_f32.p : nullptr,
+                                       pcm16 ? pl->out_pcm.p : nullptr, pcm_policy, s));
+    if (audio_f32) FMRX_HIP(hipMemcpyAsync(audio_f32, pl->out_f32.p, nch * n_au * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (pcm16) FMRX_HIP(hipMemcpyAsync(pcm16, pl->out_pcm.p, nch * n_au * sizeof(int16_t), hipMemcpyDeviceToHost, s));
+    FMRX_HIP(hipStreamSynchronize(s));
+    return FMRX_OK;
+}
+
+int fmrx_pipeline_read_tap(fmrx_pipeline *pl, int which, float *out, size_t *n)
+{
+    if (!pl || !n) return fail(FMRX_EINVAL, "read_tap: null argument");
+    FMRX_HIP(hipSetDevice(pl->device));
+    FMRX_HIP(hipDeviceSynchronize());
+    const size_t n_if = pl->last_n_if, n_au = pl->last_n_audio;
+    const float *src = nullptr;
+    size_t cnt = 0;
+    const bool st = pl->channels == 2;
+    switch (which) {
+    case FMRX_TAP_IF_I:
+    case FMRX_TAP_IF_Q: cnt = n_if; break;
+    case FMRX_TAP_DEMOD: src = pl->demod.p + pl->Hd; cnt = n_if; break;
+    case FMRX_TAP_MONO: src = pl->mono.p; cnt = n_au; break;
+    case FMRX_TAP_CARRIER: if (st) { src = pl->carrier.p; cnt = n_if; } break;
+    case FMRX_TAP_STEREO_BPF: if (st) { src = pl->bpf.p; cnt = n_if; } break;
+    case FMRX_TAP_PLL: if (st) { src = pl->pll.p; cnt = n_if + 1; } break;
+    case FMRX_TAP_MIXER: if (st) { src = pl->mixer.p + pl->Ha; cnt = n_if; } break;
+    case FMRX_TAP_STEREO_FINAL: if (st) { src = pl->st_final.p; cnt = n_au; } break;
+    default: return fail(FMRX_EINVAL, "read_tap: unknown tap %d", which);
+    }
+    if (which >= FMRX_TAP_CARRIER && !st) return fail(FMRX_EINVAL, "read_tap: tap %d exists only in stereo pipelines", which);
+    *n = cnt;
+    if (!out || cnt == 0) return FMRX_OK;
+    if (which == FMRX_TAP_IF_I || which == FMRX_TAP_IF_Q) {
+        // NOTE: demod of the block already shifted the history; IF is intact
+        std::vector<float> z(2 * cnt);
+        FMRX_HIP(hipMemcpy(z.data(), pl->ifb.p, 2 * cnt * sizeof(float), hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < cnt; k++) out[k] = z[2 * k + (which == FMRX_TAP_IF_Q)];
+        return FMRX_OK;
+    }
+    FMRX_HIP(hipMemcpy(out, src, cnt * sizeof(float), hipMemcpyDeviceToHost));
+    return FMRX_OK;
+}
+
+// ---- carried state -----------------------------------------------------------------------
+size_t fmrx_pipeline_state_size(const fmrx_pipeline *pl)
+{
+    if (!pl) return 0;
+    size_t n = 2 * (pl->p.rf_taps - 1) + 2 + pl->Ha;
+    if (pl->channels == 2) n += 2 * (pl->St - 1) + pl->Ha + pl->delay + 6;
+    return n;
+}
+
+int fmrx_pipeline_get_state(fmrx_pipeline *pl, float *state, size_t n)
+{
+    if (!pl || !state) return fail(FMRX_EINVAL, "get_state: null argument");
+    if (n != fmrx_pipeline_state_size(pl)) return fail(FMRX_EINVAL, "get_state: expected %zu floats", fmrx_pipeline_state_size(pl));
+    FMRX_HIP(hipSetDevice(pl->device));
+    FMRX_HIP(hipDeviceSynchronize());
+    const int T = pl->p.rf_taps, hb = pl->fe.hist_bytes, live = 2 * (T - 1);
+    std::vector<uint8_t> hist(hb);
+    FMRX_HIP(hipMemcpy(hist.data(), pl->fe_hist[pl->fe_cur].p, hb, hipMemcpyDeviceToHost));
+    float *o = state;
+    for (int c = 0; c < 2; c++)
+        for (int i = 0; i < T - 1; i++) *o++ = (static_cast<int>(hist[hb - live + 2 * i + c]) - 128) / 128.0f;
+    FMRX_HIP(hipMemcpy(o, pl->prev_iq[pl->prev_cur].p, 2 * sizeof(float), hipMemcpyDeviceToHost));
+    o += 2;
+    std::vector<float> dh(pl->Hd);
+    FMRX_HIP(hipMemcpy(dh.data(), pl->demod.p, pl->Hd * sizeof(float), hipMemcpyDeviceToHost));
+    // the demod history is shared by every consumer of demod; each reference
+    // state vector is a window of it
+    const float *dend = dh.data() + pl->Hd;  // one past demod[-1]
+    // state_mono: audio FIR input is the all-passed demod: samples demod[-delay-Ha .. -delay-1]
+    std::memcpy(o, dend - pl->delay - pl->Ha, pl->Ha * sizeof(float));
+    o += pl->Ha;
+    if (pl->channels == 2) {
+        std::memcpy(o, dend - (pl->St - 1), (pl->St - 1) * sizeof(float)); o += pl->St - 1;  // state_stereo
+        std::memcpy(o, dend - (pl->St - 1), (pl->St - 1) * sizeof(float)); o += pl->St - 1;  // state_carrier
+        FMRX_HIP(hipMemcpy(o, pl->mixer.p, pl->Ha * sizeof(float), hipMemcpyDeviceToHost)); o += pl->Ha;  // state_stereofilt
+        std::memcpy(o, dend - pl->delay, pl->delay * sizeof(float)); o += pl->delay;        // state_allpass
+        FMRX_HIP(hipMemcpy(o, pl->pll_state.p, 6 * sizeof(float), hipMemcpyDeviceToHost)); o += 6;
+    }
+    return FMRX_OK;
+}
+
+int fmrx_pipeline_set_state(fmrx_pipeline *pl, const float *state, size_t n)
+{
+    if (!pl || !state) return fail(FMRX_EINVAL, "set_state: null argument");
+    if (n != fmrx_pipeline_state_size(pl)) return fail(FMRX_EINVAL, "set_state: expected %zu floats", fmrx_pipeline_state_size(pl));
+    FMRX_HIP(hipSetDevice(pl->device));
+    FMRX_HIP(hipDeviceSynchronize());
+    const int T = pl->p.rf_taps, hb = pl->fe.hist_bytes, live = 2 * (T - 1);
+    std::vector<uint8_t> hist(hb, 128);
+    const float *o = state;
+    for (int c = 0; c < 2; c++)
+        for (int i = 0; i < T - 1; i++) {
+            const float v = *o++ * 128.0f + 128.0f;
+            if (!(v >= 0.0f && v <= 255.0f) || v != static_cast<float>(static_cast<int>(v)))
+                return fail(FMRX_EINVAL, "set_state: front-end state holds a value that is not (u8-128)/128");
+            hist[hb - live + 2 * i + c] = static_cast<uint8_t>(v);
+        }
+    FMRX_HIP(hipMemcpy(pl->fe_hist[pl->fe_cur].p, hist.data(), hb, hipMemcpyHostToDevice));
+    FMRX_HIP(hipMemcpy(pl->prev_iq[pl->prev_cur].p, o, 2 * sizeof(float), hipMemcpyHostToDevice));
+    o += 2;
+    std::vector<float> dh(pl->Hd, 0.0f);
+    float *dend = dh.data() + pl->Hd;
+    const float *s_mono = o; o += pl->Ha;
+    if (pl->channels == 2) {
+        const float *s_st = o; o += pl->St - 1;
+        const float *s_car = o; o += pl->St - 1;
+        const float *s_sf = o; o += pl->Ha;
+        const float *s_ap = o; o += pl->delay;
+        // widest window first, then the ones that must agree with it
+        std::memcpy(dend - pl->delay - pl->Ha, s_mono, pl->Ha * sizeof(float));
+        std::memcpy(dend - pl->delay, s_ap, pl->delay * sizeof(float));
+        std::memcpy(dend - (pl->St - 1), s_st, (pl->St - 1) * sizeof(float));
+        (void)s_car;  // identical to state_stereo by construction (same input stream)
+        FMRX_HIP(hipMemcpy(pl->mixer.p, s_sf, pl->Ha * sizeof(float), hipMemcpyHostToDevice));
+        FMRX_HIP(hipMemcpy(pl->pll_state.p, o, 6 * sizeof(float), hipMemcpyHostToDevice));
+        o += 6;
+    } else {
+        std::memcpy(dend - pl->Ha, s_mono, pl->Ha * sizeof(float));
+    }
+    FMRX_HIP(hipMemcpy(pl->demod.p, dh.data(), pl->Hd * sizeof(float), hipMemcpyHostToDevice));
+    return FMRX_OK;
+}
+
+int fmrx_pipeline_last_timing(fmrx_pipeline *pl, float *t)
+{
+    int count = 0;
+    FMRX_TRY(fmrx_pipeline_timing_sum(pl, t, &count, 1));
+    return FMRX_OK;
+}
+
+int fmrx_pipeline_timing_sum(fmrx_pipeline *pl, float *t, int *count, int max_calls)
+{
+    if (!pl || !t || !count) return fail(FMRX_EINVAL, "timing_sum: null argument");
+    if (pl->calls == 0) return fail(FMRX_EINVAL, "timing: no profiled process call (enable with fmrx_pipeline_set_profiling)");
+    unsigned long n = pl->calls < static_cast<unsigned long>(fmrx_pipeline::kRing) ? pl->calls : fmrx_pipeline::kRing;
+    if (max_calls > 0 && static_cast<unsigned long>(max_calls) < n) n = max_calls;
+    t[0] = t[1] = t[2] = t[3] = 0.0f;
+    for (unsigned long i = 0; i < n; i++) {
+        hipEvent_t *ev = pl->ev[(pl->calls - 1 - i) % fmrx_pipeline::kRing];
+        FMRX_HIP(hipEventSynchronize(ev[3]));
+        float d[4];
+        FMRX_HIP(hipEventElapsedTime(&d[0], ev[0], ev[1]));
+        FMRX_HIP(hipEventElapsedTime(&d[1], ev[1], ev[2]));
+        FMRX_HIP(hipEventElapsedTime(&d[2], ev[2], ev[3]));
+        FMRX_HIP(hipEventElapsedTime(&d[3], ev[0], ev[3]));
+        for (int k = 0; k < 4; k++) t[k] += d[k];
+    }
+    *count = static_cast<int>(n);
+    return FMRX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+"""Host-side checks that run without a GPU: the C-ABI library loads and
+exports every symbol include/fmrx.h declares, the coefficient API is
+bit-compatible with the golden vectors, argument validation returns error
+codes (nothing exits, nothing falls back to a CPU path)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def no_gpu(fmrx):
+    return fmrx.device_count() == 0
+
+
+def test_library_exports_every_declared_symbol(fmrx):
+    hdr = open(fmrx.HEADER_PATH).read()
+    declared = set(re.findall(r"FMRX_API\s+[\w\s\*]+?\b(fmrx_\w+)\s*\(", hdr))
+    assert len(declared) >= 40
+    lib = ctypes.CDLL(fmrx.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+
+
+def test_no_oracle_in_product(fmrx):
+    """The product must not link, load or import anything under oracle/."""
+    out = subprocess.run(["ldd", fmrx.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out and "fmref" not in out
+    pkg = os.path.dirname(fmrx.LIB_PATH)
+    for dirpath, _, files in os.walk(os.path.dirname(pkg)):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "liboracle" not in txt and "fm_oracle" not in txt and "_oracle" not in txt, f
+
+
+def test_coefficients_bit_exact(fmrx):
+    g = np.load(os.path.join(G, "coeffs.npz"))
+    for k in g.files:
+        parts = k.split("_")
+        if parts[0] == "lpf":
+            got = fmrx.impulseResponseLPF(float(parts[1]), float(parts[2]), int(parts[3]))
+        else:
+            got = fmrx.bandPass(float(parts[1]), float(parts[2]), float(parts[3]), int(parts[4]))
+        np.testing.assert_array_equal(got.view(np.uint32), g[k].view(np.uint32), err_msg=k)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_mode_table(fmrx, oracle, mode):
+    for taps in [(101, 101, 101), (151, 101, 151), (13, 13, 13)]:
+        a, b = fmrx.modeParams(mode, *taps), oracle.mode_params(mode, *taps)
+        for f, _ in a._fields_:
+            assert getattr(a, f) == getattr(b, f), f
+    # SURVEY A.1
+    assert fmrx.modeParams(0).block_bytes == 102400 and fmrx.modeParams(1).block_bytes == 61440
+    assert fmrx.modeParams(2).block_bytes == 112000 and fmrx.modeParams(3).block_bytes == 134400
+    assert fmrx.modeParams(2).audio_taps == 14847 and fmrx.modeParams(3).audio_taps == 44541
+
+
+def test_bad_arguments_return_codes(fmrx):
+    with pytest.raises(fmrx.FmrxError) as e:
+        fmrx.modeParams(4)
+    assert e.value.code == fmrx.EINVAL
+    with pytest.raises(fmrx.FmrxError):
+        fmrx.modeParams(0, rf_taps=1)
+    with pytest.raises(fmrx.FmrxError):
+        fmrx.modeParams(3, base_audio_taps=200)  # 200*441 > 65535 (unsigned short in the reference)
+    x, h = np.zeros(50, np.float32), np.zeros(101, np.float32)
+    with pytest.raises(fmrx.FmrxError) as e:  # block shorter than taps-1
+        fmrx.convolveBlockFastFIR(x, h, np.zeros(100, np.float32), 5)
+    assert e.value.code == fmrx.EINVAL
+    with pytest.raises(fmrx.FmrxError) as e:
+        fmrx.convolveBlockFastFIR(np.zeros(500, np.float32), h, np.zeros(100, np.float32), 0)
+    assert e.value.code == fmrx.EINVAL
+    with pytest.raises(fmrx.FmrxError):
+        fmrx.allPass(np.zeros(10, np.float32), np.zeros(50, np.float32))
+
+
+def test_no_cpu_fallback_without_device(fmrx):
+    """On a box without a GPU every compute entry point must fail loudly (ENODEV)."""
+    if not no_gpu(fmrx):
+        pytest.skip("a GPU is present")
+    x, h = np.zeros(500, np.float32), np.ones(101, np.float32)
+    for call in (lambda: fmrx.convolveBlockFastFIR(x, h, np.zeros(100, np.float32), 5),
+                 lambda: fmrx.convolveFIR(x, h),
+                 lambda: fmrx.fmDemod(x, x),
+                 lambda: fmrx.readBlockData(np.zeros(16, np.uint8)),
+                 lambda: fmrx.frontEndFIR(np.zeros(4000, np.uint8), h, 10),
+                 lambda: fmrx.Pipeline(0, 1)):
+        with pytest.raises(fmrx.FmrxError) as e:
+            call()
+        assert e.value.code == fmrx.ENODEV
+
+
+def test_cli_usage_and_modes(fmrx):
+    exe = os.path.join(os.path.dirname(fmrx.LIB_PATH), "fmrx_project")
+    assert os.path.exists(exe)
+    r = subprocess.run([exe, "7"], input=b"", capture_output=True)
+    assert r.returncode == 1 and b"Wrong mode" in r.stderr and r.stdout == b""
+    r = subprocess.run([exe, "0", "1", "2"], input=b"", capture_output=True)
+    assert r.returncode == 1 and b"Usage" in r.stderr
+    if no_gpu(fmrx):
+        r = subprocess.run([exe, "0", "1"], input=b"", capture_output=True)
+        assert r.returncode == 2 and b"no usable HIP device" in r.stderr and r.stdout == b""
