@@ -42,6 +42,28 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
         "(or `make -C software-defined-radio_amd/csrc`). There is no Python/CPU fallback.")
 
+
+
+def _share_hip_runtime_with_torch() -> None:
+    """torch wheels bundle their own libamdhip64.so.7; libfmrx.so needs the same
+    soname from /opt/rocm.  Whichever loads first serves both, and torch does not
+    come up on the system copy.  Load torch's copy first (without importing
+    torch) so the two always share one runtime, whatever the import order."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.submodule_search_locations:
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
+_share_hip_runtime_with_torch()
 lib = C.CDLL(LIB_PATH)
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")

@@ -73,7 +73,6 @@ struct FePlan {
     int hist_bytes = 0;        // bytes of u8 history the kernel reads before the block (multiple of 16)
     DevBuf<float> table;       // fast-path table
     DevBuf<float> h;           // plain taps (generic path)
-    float c0 = 0.0f;           // accumulator seed: -(sum of taps)
 };
 int fe_plan_init(FePlan &pl, const float *h, int taps, int decim);
 // d_hist: hist_bytes bytes whose LAST 2*(taps-1) hold the previous samples.

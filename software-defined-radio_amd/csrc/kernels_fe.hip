@@ -28,8 +28,13 @@
 //    the R+ceil(T/D)-1 window samples j = p + D*i, each converted once per
 //    branch and reused by up to R outputs.  Per 8 outputs: 808 v_pk_fma_f32 +
 //    342 v_cvt (T=101, D=10), i.e. ~70 % of VALU issue is useful FMA.
-//  * (u-128)/128 is folded away: taps are pre-scaled by 1/128 (exact) and the
-//    accumulators start at -sum(h), so sum h'(u-128) = sum h'u - 128*sum h'.
+//  * (u-128)/128 costs nothing per tap: the staging pass flips the top bit of
+//    every byte (u ^ 0x80 is u-128 as a signed byte; one v_xor per 4 samples,
+//    once per tile), the window bytes are converted with the sign-extending
+//    v_cvt_f32_i32 (SDWA byte select), and the taps are pre-scaled by 1/128
+//    (exact).  Every product h[n]*(u-128)/128 is then the reference's product
+//    bit for bit, silence (u = 128) gives exact zeros, and the rounding error
+//    scales with the signal instead of with the 128 offset.
 //
 // Numerics: one fused multiply-add per tap, taps visited branch by branch
 // instead of n = 0..T-1; the result differs from the reference's sequential
@@ -70,7 +75,7 @@ struct FeCfg {
 // output r with tap q = i - r of branch p.
 template <int T, int D, int R, int NT>
 __global__ __launch_bounds__(NT) void fe_fir_kernel(const uint8_t *__restrict__ x, const uint8_t *__restrict__ hist,
-                                                     long n_bytes, const float *__restrict__ table, float c0,
+                                                     long n_bytes, const float *__restrict__ table,
                                                      f2 *__restrict__ y, long n_out)
 {
     using C = FeCfg<T, D, R, NT>;
@@ -81,7 +86,8 @@ __global__ __launch_bounds__(NT) void fe_fir_kernel(const uint8_t *__restrict__ 
 
     // ---- stage the tile's raw bytes: coalesced 16 B per lane ----
     constexpr int NCHUNK = C::TILE_BYTES / 16;
-    const u4 silence = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};  // u8 128 == 0.0f
+    const u4 silence = {0u, 0u, 0u, 0u};  // u8 128 == 0.0f == signed byte 0
+    const uint32_t flip = 0x80808080u;    // u ^ 0x80 = (u - 128) as int8
 #pragma unroll
     for (int c0i = 0; c0i < NCHUNK; c0i += NT) {
         const int c = c0i + t;
@@ -89,9 +95,9 @@ __global__ __launch_bounds__(NT) void fe_fir_kernel(const uint8_t *__restrict__ 
             const long g = wbyte0 + 16L * c;
             u4 v = silence;
             if (g >= 0) {
-                if (g + 16 <= n_bytes) v = *reinterpret_cast<const u4 *>(x + g);
+                if (g + 16 <= n_bytes) v = *reinterpret_cast<const u4 *>(x + g) ^ flip;
             } else if (hist) {
-                v = *reinterpret_cast<const u4 *>(hist + (g + C::HB));
+                v = *reinterpret_cast<const u4 *>(hist + (g + C::HB)) ^ flip;
             }
             lds[c] = v;
         }
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(NT) void fe_fir_kernel(const uint8_t *__restrict__ 
 
     f2 acc[R];
 #pragma unroll
-    for (int r = 0; r < R; r++) acc[r] = (f2){c0, c0};
+    for (int r = 0; r < R; r++) acc[r] = (f2){0.0f, 0.0f};
 
 #pragma unroll
     for (int p = 0; p < D; p++) {
@@ -136,12 +142,13 @@ __global__ __launch_bounds__(NT) void fe_fir_kernel(const uint8_t *__restrict__ 
                     const int bo = 2 * (j + C::LEAD);
                     const uint32_t w = raw[bo / 4];
                     f2 xs;
+                    // v_cvt_f32_i32_sdwa sext(w) src0_sel:BYTE_n
                     if ((bo % 4) == 0) {
-                        xs.x = static_cast<float>(w & 0xffu);          // v_cvt_f32_ubyte0
-                        xs.y = static_cast<float>((w >> 8) & 0xffu);   // v_cvt_f32_ubyte1
+                        xs.x = static_cast<float>(static_cast<int8_t>(w & 0xffu));
+                        xs.y = static_cast<float>(static_cast<int8_t>((w >> 8) & 0xffu));
                     } else {
-                        xs.x = static_cast<float>((w >> 16) & 0xffu);  // v_cvt_f32_ubyte2
-                        xs.y = static_cast<float>(w >> 24);            // v_cvt_f32_ubyte3
+                        xs.x = static_cast<float>(static_cast<int8_t>((w >> 16) & 0xffu));
+                        xs.y = static_cast<float>(static_cast<int8_t>(w >> 24));
                     }
 #pragma unroll
                     for (int r = 0; r < R; r++) {
@@ -182,7 +189,7 @@ int launch_fast(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const u
     const long n_out = static_cast<long>(n_samples / D);
     const unsigned grid = static_cast<unsigned>((n_out + C::NOUT - 1) / C::NOUT);
     hipLaunchKernelGGL((fe_fir_kernel<T, D, R, NT>), dim3(grid), dim3(NT), C::TILE_BYTES, stream, d_iq, d_hist,
-                       static_cast<long>(2 * n_samples), pl.table.p, pl.c0, reinterpret_cast<f2 *>(d_if), n_out);
+                       static_cast<long>(2 * n_samples), pl.table.p, reinterpret_cast<f2 *>(d_if), n_out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FMRX_EHIP, "launch fe_fir_kernel<%d,%d>: %s", T, D, hipGetErrorString(e));
     return FMRX_OK;
@@ -218,9 +225,6 @@ int fe_plan_init(FePlan &pl, const float *h, int taps, int decim)
     pl.decim = decim;
     pl.hist_bytes = fe_hist_bytes(taps);
     pl.fast = false;
-    double sum = 0.0;
-    for (int i = 0; i < taps; i++) sum += static_cast<double>(h[i]);
-    pl.c0 = static_cast<float>(-sum);
     FMRX_TRY(pl.h.alloc(taps));
     FMRX_HIP(hipMemcpy(pl.h.p, h, taps * sizeof(float), hipMemcpyHostToDevice));
     std::vector<float> tab;

@@ -15,7 +15,7 @@ step() {  # name, timeout, command...
 rocminfo | grep -E "Marketing Name|gfx9" | head -4 > gpurun_out/device.log 2>&1
 nproc >> gpurun_out/device.log
 step smoke 300 python -c "import __graft_entry__ as g; g.smoke()"
-step pytest_gpu 600 python -m pytest tests -m gpu -q -x --timeout 300
+step pytest_gpu 600 python -m pytest tests -m gpu -q --timeout 300 -rA
 step valu 120 ./tools/microbench/valu_rates
 step bench 420 python bench.py --steps 20 --warmup 3
 tail -3 gpurun_out/smoke.log; tail -15 gpurun_out/pytest_gpu.log; tail -3 gpurun_out/bench.log

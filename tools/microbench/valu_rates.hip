@@ -39,6 +39,11 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float hs, long l
                 }
                 if (OP == 5) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(x), "v"(h2));  // VGPR tap
                 if (OP == 6) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(acc[i]) : "v"(x), "v"(h2));
+                if (OP == 7) asm volatile("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(tmp[i & 3]) : "v"(raw));
+                if (OP == 8) {  // front-end mix with the signed (SDWA) conversion
+                    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc[i]) : "v"(x), "s"(h2));
+                    if (i < 3 || (i == 3 && (u & 1))) asm volatile("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(tmp[i & 3]) : "v"(raw));
+                }
             }
         }
     }
@@ -81,7 +86,7 @@ int run(const char *name, int waves_per_simd, double ops_per_inner)
 
 int main()
 {
-    for (int w : {1, 2, 4, 8}) {
+    for (int w : {1, 3, 8}) {
         if (run<0>("v_fma_f32 (sgpr src)", w, 1)) return 1;
         if (run<1>("v_pk_fma_f32 (sgpr pair, op_sel)", w, 1)) return 1;
         if (run<5>("v_pk_fma_f32 (vgpr tap)", w, 1)) return 1;
@@ -89,6 +94,8 @@ int main()
         if (run<2>("v_cvt_f32_ubyte1", w, 1)) return 1;
         if (run<3>("v_fma_mix_f32", w, 1)) return 1;
         if (run<4>("mix 8 pk_fma : 3.5 cvt", w, 1.0 + 3.5 / 8.0)) return 1;
+        if (run<7>("v_cvt_f32_i32_sdwa sext byte", w, 1)) return 1;
+        if (run<8>("mix 8 pk_fma : 3.5 cvt_sdwa", w, 1.0 + 3.5 / 8.0)) return 1;
         printf("\n");
     }
     return 0;
