@@ -44,26 +44,24 @@ if not os.path.exists(LIB_PATH):
 
 
 
-def _share_hip_runtime_with_torch() -> None:
-    """torch wheels bundle their own libamdhip64.so.7; libfmrx.so needs the same
-    soname from /opt/rocm.  Whichever loads first serves both, and torch does not
-    come up on the system copy.  Load torch's copy first (without importing
-    torch) so the two always share one runtime, whatever the import order."""
+def _load_torch_first() -> None:
+    """torch wheels bundle their own libamdhip64.so.7 and libfmrx.so needs the same
+    soname from /opt/rocm; whichever is loaded first serves both.  torch -> libfmrx is
+    the order that works (bench.py); the other order hangs inside `import torch`.
+    So when torch is installed, import it before the library is loaded.  Set
+    FMRX_NO_TORCH=1 to skip this in a torch-free process."""
     import importlib.util
     import sys
-    if "torch" in sys.modules:
+    if "torch" in sys.modules or os.environ.get("FMRX_NO_TORCH") == "1":
         return
     try:
-        spec = importlib.util.find_spec("torch")
-    except (ImportError, ValueError):
-        spec = None
-    if spec and spec.submodule_search_locations:
-        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
-        if os.path.exists(cand):
-            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
+    except Exception:  # a broken torch install must not take the DSP library down with it
+        pass
 
 
-_share_hip_runtime_with_torch()
+_load_torch_first()
 lib = C.CDLL(LIB_PATH)
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")

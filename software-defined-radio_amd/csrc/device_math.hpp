@@ -1,0 +1,54 @@
+// device_math.hpp -- small __device__ helpers shared by the kernel files, so
+// that a value computed by two different kernels (e.g. a discriminator sample
+// computed inside the fused audio kernel and again by the history-tail kernel)
+// is the same bit pattern.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fmrx {
+
+// FM discriminator, reference evaluation order (src/filter.cpp:254-259):
+// separate rounded products, one IEEE divide.  Compile the including file
+// with contraction off for this to stay bit-compatible.
+__device__ __forceinline__ float demod_exact(float i, float q, float pi, float pq)
+{
+    const float ii = __fmul_rn(i, i), qq = __fmul_rn(q, q);
+    const float den = __fadd_rn(ii, qq);
+    if (den == 0.0f) return 0.0f;
+    const float a = __fmul_rn(i, __fsub_rn(q, pq));
+    const float b = __fmul_rn(q, __fsub_rn(i, pi));
+    return __fdiv_rn(__fsub_rn(a, b), den);
+}
+
+// Throughput form used by the specialised pipeline: FMAs and a 1-ulp hardware
+// reciprocal (v_rcp_f32) instead of the ~10-instruction IEEE divide.  Same
+// den == 0 -> 0 rule; |error| <= ~2 ulp of the quotient.  Tiny denominators
+// (where v_rcp_f32 would leave the normal range) take the exact path.
+__device__ __forceinline__ float demod_fast(float i, float q, float pi, float pq)
+{
+    const float den = __fmaf_rn(q, q, __fmul_rn(i, i));
+    if (den == 0.0f) return 0.0f;
+    const float num = __fmaf_rn(i, __fsub_rn(q, pq), -__fmul_rn(q, __fsub_rn(i, pi)));
+    if (den < 1e-30f) return __fdiv_rn(num, den);
+    return __fmul_rn(num, __builtin_amdgcn_rcpf(den));
+}
+
+// PCM pack of src/threadMonoOnly.cpp:185-191: NaN -> 0 else (short)(a*16384).
+// wrap: what the compiled reference does out of range (cvttss2si, low 16 bits).
+__device__ __forceinline__ int16_t pcm_pack(float a, int wrap)
+{
+    if (a != a) return 0;
+    const float s = __fmul_rn(a, 16384.0f);
+    if (wrap) {
+        int v;
+        if (s >= 2147483648.0f || s < -2147483648.0f) v = static_cast<int>(0x80000000u);
+        else v = static_cast<int>(s);
+        return static_cast<int16_t>(static_cast<uint16_t>(static_cast<uint32_t>(v)));
+    }
+    if (s >= 32767.0f) return 32767;
+    if (s <= -32768.0f) return -32768;
+    return static_cast<int16_t>(s);
+}
+
+}  // namespace fmrx

@@ -91,8 +91,15 @@ struct AudioPlan {
 int audio_plan_init(AudioPlan &pl, const float *h, int taps, int decim);
 // y[k] = sum_n h[n] * x[decim*k - n - delay]; x points at the block start and
 // x[-(taps-1+delay) .. -1] must be readable history.
-int audio_fir_launch(const AudioPlan &pl, const float *d_x, size_t n_in, int delay, float *d_y, hipStream_t stream,
-                     bool force_generic);
+// Optionally also writes s16 PCM (d_pcm != nullptr).
+int audio_fir_launch(const AudioPlan &pl, const float *d_x, size_t n_in, int delay, float *d_y, int16_t *d_pcm, int wrap,
+                     hipStream_t stream, bool force_generic);
+// Fused discriminator + audio FIR (+ PCM) straight from the IF I/Q pairs: d_if
+// = interleaved IF block, d_prev = IF[-1] (float2), d_demod_blk = pointer to
+// where demod[0] of this block lives (demod history at negative indices).
+// Only for plans with fast == true.
+int audio_demod_fir_launch(const AudioPlan &pl, const float *d_if, const float *d_prev, const float *d_demod_blk,
+                           size_t n_if, int delay, float *d_y, int16_t *d_pcm, int wrap, hipStream_t stream);
 
 // ---- generic kernels (kernels_generic.hip) ----------------------------------
 // y[k] = sum_{n<taps} h[n]*x[decim*k - n], sequential mul+add in n (bit-compatible
@@ -105,7 +112,9 @@ int k_fe_generic(const uint8_t *d_iq, const uint8_t *d_hist, int hist_bytes, siz
 int k_resample_generic(const float *d_x, size_t n_in, const float *d_h, int taps, int decim, int upsamp, float *d_y,
                        hipStream_t s);
 // demod[k] from interleaved IF (I,Q); IF[-1] = *d_prev (float2). Also stores IF[n-1] to d_prev_out when non-null.
-int k_fm_demod_if(const float *d_if, size_t n, const float *d_prev, float *d_prev_out, float *d_demod, hipStream_t s);
+// fast != 0: the arithmetic of the fused audio kernel (demod_fast) instead of the reference order
+int k_fm_demod_if(const float *d_if, size_t n, const float *d_prev, float *d_prev_out, float *d_demod, int fast,
+                  hipStream_t s);
 int k_fm_demod_planar(const float *d_i, const float *d_q, size_t n, float prev_i, float prev_q, float *d_demod,
                       hipStream_t s);
 int k_u8_to_f32(const uint8_t *d_raw, size_t n, float *d_out, hipStream_t s);

@@ -1,12 +1,185 @@
-// kernels_audio.hip -- audio-rate decimating FIR on the FM-demodulated stream
-// (RF_MONO / RF_STEREO: src/project.cpp:346, 219, 257 -> src/filter.cpp:158-188).
+// kernels_audio.hip -- the audio-rate stage: FM discriminator fused into the
+// decimating low-pass FIR, plus s16 packing, one kernel.
 //
-// Round-1 state: this stage (~10 % of the mono path's MACs) runs on
-// the generic kernel; the register-window kernel of kernels_fe.hip is the
-// template for its specialised version.
+// Replaces fmDemod (src/project.cpp:128 -> src/filter.cpp:248-266), the audio
+// convolveBlockFastFIR of RF_MONO / RF_STEREO (src/project.cpp:346, 219, 257 ->
+// src/filter.cpp:158-188) and the PCM conversion (src/threadMonoOnly.cpp:185-191).
+//
+// Same register-window / packed-FMA structure as kernels_fe.hip, with two
+// changes forced by the data: (1) the input is one real stream, so the two
+// halves of v_pk_fma_f32 carry two OUTPUTS that are HALF = NT*R apart (the tile
+// is split into a low and a high half and staged in LDS as (lo, hi) float
+// pairs); (2) float windows are too big for registers (136 samples x 2), so the
+// tile is staged PHASE-MAJOR -- LDS[p][i] = pair of sample p + D*i -- and a
+// thread streams one polyphase branch at a time: R+ceil(T/D)-1 consecutive
+// pairs (ds_read_b128, chunk-padded so lanes 64 B apart do not share a bank).
+//
+// Staging computes the discriminator on the fly from the IF I/Q pairs the
+// front end wrote (SRC_IF), so the demodulated stream is never written to or
+// read back from HBM in the mono path; samples before the block come from the
+// carried demod history.  SRC_FLOAT stages a plain float stream (the stereo
+// mixer output) through the same code.
+//
+// Numerics: one FMA per tap in polyphase order (as the front end); the
+// discriminator uses demod_fast (device_math.hpp).  The generic kernels keep
+// the reference's exact order and serve as the bit-compatible path.
+#include "device_math.hpp"
 #include "fmrx_internal.hpp"
 
 namespace fmrx {
+
+namespace {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f8 __attribute__((ext_vector_type(8)));
+
+constexpr int kQC = 12;
+enum { SRC_IF = 0, SRC_FLOAT = 1 };
+
+template <int T, int D, int R, int NT>
+struct AuCfg {
+    static constexpr int QT = (T + D - 1) / D;
+    static constexpr int NC = (QT + kQC - 1) / kQC;
+    static constexpr int HALF = NT * R;                 // outputs per half tile
+    static constexpr int WL = D * (HALF - 1) + T;       // input samples one half needs
+    static constexpr int NI = HALF + QT - 1;            // pairs per polyphase branch
+    static constexpr int CHB = R * 8 + 16;              // bytes per padded chunk of R pairs
+    static constexpr int NCHK = NI / R + 1;               // +1: the last b128 of the last thread may touch pair NI
+    static constexpr int PH_BYTES = NCHK * CHB;
+    static constexpr int LDS_BYTES = D * PH_BYTES;
+    static constexpr int WT = D * (R - 1) + T;          // samples one thread's outputs span
+    static constexpr int NPAIR = R + QT - 1;            // pairs a thread reads per branch
+    static constexpr int NRD = (NPAIR + 1) / 2;         // ds_read_b128 per branch
+    static constexpr int TABLE = D * NC * kQC;
+    static_assert(R % 2 == 0, "pairs are read two at a time");
+    static_assert(LDS_BYTES <= 64 * 1024, "tile exceeds the default LDS limit");
+};
+
+template <int T, int D, int R, int NT, int SRC>
+__global__ __launch_bounds__(NT) void audio_fir_kernel(const float2 *__restrict__ z, const float2 *__restrict__ prev,
+                                                        const float *__restrict__ xh, long n_in, int delay,
+                                                        const float *__restrict__ table, float *__restrict__ y,
+                                                        int16_t *__restrict__ pcm, int wrap, long n_out)
+{
+    using C = AuCfg<T, D, R, NT>;
+    extern __shared__ f4 lds4[];
+    uint8_t *ldsb = reinterpret_cast<uint8_t *>(lds4);
+    const int t = threadIdx.x;
+    const long a0 = static_cast<long>(blockIdx.x) * (2 * C::HALF);   // first output of the low half
+    const long gbase = D * a0 - (T - 1) - delay;                      // input index of window sample 0 (low half)
+
+    // ---- stage both half-windows, phase-major, computing the discriminator on the way ----
+#pragma unroll 4
+    for (int jj = t; jj < 2 * C::WL; jj += NT) {
+        const int half = jj >= C::WL ? 1 : 0;
+        const int j = jj - half * C::WL;
+        const long g = gbase + static_cast<long>(half) * (D * C::HALF) + j;
+        float v = 0.0f;
+        if (g < 0) {
+            v = xh[g];  // carried history sits in front of the block
+        } else if (g < n_in) {
+            if (SRC == SRC_IF) {
+                const float2 c = z[g];
+                const float2 pz = g ? z[g - 1] : *prev;
+                v = demod_fast(c.x, c.y, pz.x, pz.y);
+            } else {
+                v = xh[g];
+            }
+        }
+        const int p = j % D, i = j / D;
+        *reinterpret_cast<float *>(ldsb + p * C::PH_BYTES + (i / R) * C::CHB + (i % R) * 8 + half * 4) = v;
+    }
+    __syncthreads();
+
+    f2 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = (f2){0.0f, 0.0f};
+
+#pragma unroll
+    for (int p = 0; p < D; p++) {
+        // the thread's pairs of branch p: i = t*R + ii, ii = 0 .. NPAIR-1
+        f2 xs[2 * C::NRD];
+#pragma unroll
+        for (int k = 0; k < C::NRD; k++) {
+            const int ii = 2 * k;
+            const f4 v = *reinterpret_cast<const f4 *>(ldsb + p * C::PH_BYTES + (t + ii / R) * C::CHB + (ii % R) * 8);
+            xs[ii] = (f2){v.x, v.y};
+            xs[ii + 1] = (f2){v.z, v.w};
+        }
+#pragma unroll
+        for (int c = 0; c < C::NC; c++) {
+            f8 ha;
+            f4 hb;
+            asm volatile("s_load_dwordx8 %0, %2, %3\n\ts_load_dwordx4 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&s"(ha), "=&s"(hb)
+                         : "s"(table), "i"((p * C::NC + c) * kQC * 4), "i"((p * C::NC + c) * kQC * 4 + 32));
+            const float hq[kQC] = {ha[0], ha[1], ha[2], ha[3], ha[4], ha[5], ha[6], ha[7], hb[0], hb[1], hb[2], hb[3]};
+#pragma unroll
+            for (int s = 0; s < R + kQC - 1; s++) {
+                const int ii = c * kQC + s;
+                if (ii < C::NPAIR && p + D * ii < C::WT) {
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int q = ii - r;
+                        if (q >= c * kQC && q < (c + 1) * kQC && p + D * q < T)
+                            acc[r] = __builtin_elementwise_fma(xs[ii], (f2){hq[q - c * kQC], hq[q - c * kQC]}, acc[r]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) asm volatile("" : "+v"(acc[r]));
+        }
+    }
+
+    // ---- R consecutive outputs in each half; f32 and/or s16 ----
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const long k = a0 + static_cast<long>(half) * C::HALF + static_cast<long>(t) * R;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const float v = half ? acc[r].y : acc[r].x;
+            if (k + r < n_out) {
+                if (y) y[k + r] = v;
+                if (pcm) pcm[k + r] = pcm_pack(v, wrap);
+            }
+        }
+    }
+}
+
+template <int T, int D, int SRC>
+int launch_fast(const AudioPlan &pl, const float *d_if, const float *d_prev, const float *d_x, size_t n_in, int delay,
+                float *d_y, int16_t *d_pcm, int wrap, hipStream_t stream)
+{
+    constexpr int R = 8, NT = 128;
+    using C = AuCfg<T, D, R, NT>;
+    const long n_out = static_cast<long>(n_in / D);
+    const unsigned grid = static_cast<unsigned>((n_out + 2 * C::HALF - 1) / (2 * C::HALF));
+    hipLaunchKernelGGL((audio_fir_kernel<T, D, R, NT, SRC>), dim3(grid), dim3(NT), C::LDS_BYTES, stream,
+                       reinterpret_cast<const float2 *>(d_if), reinterpret_cast<const float2 *>(d_prev), d_x,
+                       static_cast<long>(n_in), delay, pl.table.p, d_y, d_pcm, wrap, n_out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FMRX_EHIP, "launch audio_fir_kernel<%d,%d>: %s", T, D, hipGetErrorString(e));
+    return FMRX_OK;
+}
+
+template <int T, int D>
+void build_table(const float *h, std::vector<float> &tab)
+{
+    using C = AuCfg<T, D, 8, 128>;
+    tab.assign(C::TABLE, 0.0f);
+    for (int p = 0; p < D; p++)
+        for (int q = 0; q < C::NC * kQC; q++) {
+            const int m = p + D * q;
+            if (m < T) tab[p * C::NC * kQC + q] = h[T - 1 - m];
+        }
+}
+
+// audio taps the reference ships (101: threadMonoOnly.cpp:229-232, 13: project.cpp:424-427)
+// x the audio_decim of its integer-decimation modes 0 and 1 (5, 6)
+#define FMRX_AUDIO_CASES(X) X(101, 5) X(101, 6) X(13, 5) X(13, 6)
+
+}  // namespace
 
 int audio_plan_init(AudioPlan &pl, const float *h, int taps, int decim)
 {
@@ -15,13 +188,47 @@ int audio_plan_init(AudioPlan &pl, const float *h, int taps, int decim)
     pl.fast = false;
     FMRX_TRY(pl.h.alloc(taps));
     FMRX_HIP(hipMemcpy(pl.h.p, h, taps * sizeof(float), hipMemcpyHostToDevice));
+    std::vector<float> tab;
+#define X(T_, D_)                    \
+    if (taps == T_ && decim == D_) { \
+        build_table<T_, D_>(h, tab); \
+        pl.fast = true;              \
+    }
+    FMRX_AUDIO_CASES(X)
+#undef X
+    if (pl.fast) {
+        FMRX_TRY(pl.table.alloc(tab.size()));
+        FMRX_HIP(hipMemcpy(pl.table.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     return FMRX_OK;
 }
 
-int audio_fir_launch(const AudioPlan &pl, const float *d_x, size_t n_in, int delay, float *d_y, hipStream_t stream,
-                     bool /*force_generic*/)
+int audio_fir_launch(const AudioPlan &pl, const float *d_x, size_t n_in, int delay, float *d_y, int16_t *d_pcm, int wrap,
+                     hipStream_t stream, bool force_generic)
 {
-    return k_fir_generic(d_x - delay, n_in / pl.decim, pl.h.p, pl.taps, pl.decim, d_y, stream);
+    if (n_in / pl.decim == 0) return FMRX_OK;
+    if (pl.fast && !force_generic) {
+#define X(T_, D_) \
+    if (pl.taps == T_ && pl.decim == D_) \
+        return launch_fast<T_, D_, SRC_FLOAT>(pl, nullptr, nullptr, d_x, n_in, delay, d_y, d_pcm, wrap, stream);
+        FMRX_AUDIO_CASES(X)
+#undef X
+    }
+    FMRX_TRY(k_fir_generic(d_x - delay, n_in / pl.decim, pl.h.p, pl.taps, pl.decim, d_y, stream));
+    if (d_pcm) FMRX_TRY(k_pcm16(d_y, n_in / pl.decim, d_pcm, wrap, stream));
+    return FMRX_OK;
+}
+
+int audio_demod_fir_launch(const AudioPlan &pl, const float *d_if, const float *d_prev, const float *d_demod_blk,
+                           size_t n_if, int delay, float *d_y, int16_t *d_pcm, int wrap, hipStream_t stream)
+{
+    if (n_if / pl.decim == 0) return FMRX_OK;
+#define X(T_, D_) \
+    if (pl.taps == T_ && pl.decim == D_) \
+        return launch_fast<T_, D_, SRC_IF>(pl, d_if, d_prev, d_demod_blk, n_if, delay, d_y, d_pcm, wrap, stream);
+    FMRX_AUDIO_CASES(X)
+#undef X
+    return fail(FMRX_EINVAL, "audio_demod_fir_launch: no specialised kernel for taps=%d decim=%d", pl.taps, pl.decim);
 }
 
 }  // namespace fmrx

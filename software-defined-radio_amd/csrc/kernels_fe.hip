@@ -73,6 +73,119 @@ struct FeCfg {
 // Tap table: entry ((p*NC + c)*kQC + qq) = h[T-1 - p - D*(c*kQC+qq)] / 128, or 0
 // when that index is out of range.  Window sample j = p + D*i of a thread meets
 // output r with tap q = i - r of branch p.
+
+// taps of one (branch, group): wave-uniform, straight into SGPRs.  Inline asm keeps
+// the loads where they are written (hipcc otherwise hoists every tap load to the
+// kernel entry and spills SGPRs).  Issue and wait are separate statements so the
+// next group's taps can be in flight while this group's FMAs run.
+#define FMRX_TAPS_ISSUE(ha, hb, table, off) \
+    asm volatile("s_load_dwordx8 %0, %2, %3\n\ts_load_dwordx4 %1, %2, %4" : "=&s"(ha), "=&s"(hb) : "s"(table), "i"(off), "i"((off) + 32))
+#define FMRX_TAPS_WAIT(ha, hb) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ha), "+s"(hb))
+
+// One (branch p, tap group c) step of a thread's arithmetic; G = p*NC + c is a
+// template parameter (not a loop variable) because the scalar-load offsets must
+// be assembler immediates.  Tap registers are double-buffered: set A on even
+// steps, set B on odd ones; the other set is being loaded meanwhile.
+template <int T, int D, int R, int NT, int G>
+__device__ __forceinline__ void fe_step(const uint32_t (&raw)[FeCfg<T, D, R, NT>::NB * 4], const float *__restrict__ table,
+                                        f2 (&acc)[R], f8 &haA, f4 &hbA, f8 &haB, f4 &hbB)
+{
+    using C = FeCfg<T, D, R, NT>;
+    constexpr int NG = D * C::NC;
+    if constexpr (G < NG) {
+        constexpr int p = G / C::NC, c = G % C::NC;
+        float hq[kQC];
+        if constexpr (G % 2 == 0) {
+            FMRX_TAPS_WAIT(haA, hbA);
+            if constexpr (G + 1 < NG) FMRX_TAPS_ISSUE(haB, hbB, table, (G + 1) * kQC * 4);
+#pragma unroll
+            for (int k = 0; k < 8; k++) hq[k] = haA[k];
+#pragma unroll
+            for (int k = 0; k < 4; k++) hq[8 + k] = hbA[k];
+        } else {
+            FMRX_TAPS_WAIT(haB, hbB);
+            if constexpr (G + 1 < NG) FMRX_TAPS_ISSUE(haA, hbA, table, (G + 1) * kQC * 4);
+#pragma unroll
+            for (int k = 0; k < 8; k++) hq[k] = haB[k];
+#pragma unroll
+            for (int k = 0; k < 4; k++) hq[8 + k] = hbB[k];
+        }
+        // window samples j = p + D*i that meet taps q in [c*kQC, (c+1)*kQC)
+#pragma unroll
+        for (int ii = 0; ii < R + kQC - 1; ii++) {
+            const int i = c * kQC + ii;
+            const int j = p + D * i;
+            if (j < C::W) {
+                const int bo = 2 * (j + C::LEAD);
+                const uint32_t w = raw[bo / 4];
+                f2 xs;
+                // v_cvt_f32_i32_sdwa sext(w) src0_sel:BYTE_n
+                if ((bo % 4) == 0) {
+                    xs.x = static_cast<float>(static_cast<int8_t>(w & 0xffu));
+                    xs.y = static_cast<float>(static_cast<int8_t>((w >> 8) & 0xffu));
+                } else {
+                    xs.x = static_cast<float>(static_cast<int8_t>((w >> 16) & 0xffu));
+                    xs.y = static_cast<float>(static_cast<int8_t>(w >> 24));
+                }
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int q = i - r;
+                    if (q >= c * kQC && q < (c + 1) * kQC && p + D * q < T) {
+                        const float h = hq[q - c * kQC];
+                        acc[r] = __builtin_elementwise_fma(xs, (f2){h, h}, acc[r]);  // v_pk_fma_f32
+                    }
+                }
+            }
+        }
+        // pin this step's FMAs before the next step's (keeps the live set at one
+        // branch: ~110 VGPRs, ~45 SGPRs)
+#pragma unroll
+        for (int r = 0; r < R; r++) asm volatile("" : "+v"(acc[r]));
+        fe_step<T, D, R, NT, G + 1>(raw, table, acc, haA, hbA, haB, hbB);
+    }
+}
+
+// The arithmetic of one thread: R outputs from its register-resident byte window.
+template <int T, int D, int R, int NT>
+__device__ __forceinline__ void fe_compute(const uint32_t (&raw)[FeCfg<T, D, R, NT>::NB * 4], const float *__restrict__ table,
+                                           f2 (&acc)[R])
+{
+    f8 haA, haB;
+    f4 hbA, hbB;
+    FMRX_TAPS_ISSUE(haA, hbA, table, 0);
+    fe_step<T, D, R, NT, 0>(raw, table, acc, haA, hbA, haB, hbB);
+}
+
+// one 16-byte chunk of a tile window: block bytes, carried history, or silence
+// beyond either end; the top bit of every byte is flipped on the way (u8 -> int8)
+template <int HB>
+__device__ __forceinline__ u4 fe_fetch(const uint8_t *__restrict__ x, const uint8_t *__restrict__ hist, long n_bytes, long g)
+{
+    const uint32_t flip = 0x80808080u;
+    u4 v = {0u, 0u, 0u, 0u};  // u8 128 == 0.0f == signed byte 0
+    if (g >= 0) {
+        if (g + 16 <= n_bytes) v = *reinterpret_cast<const u4 *>(x + g) ^ flip;
+    } else if (hist) {
+        v = *reinterpret_cast<const u4 *>(hist + (g + HB)) ^ flip;
+    }
+    return v;
+}
+
+template <int R>
+__device__ __forceinline__ void fe_store(f2 *__restrict__ y, long kt, long n_out, const f2 (&acc)[R])
+{
+    if (kt + R <= n_out) {
+        f4 *dst = reinterpret_cast<f4 *>(y + kt);
+#pragma unroll
+        for (int r = 0; r < R; r += 2) dst[r / 2] = (f4){acc[r].x, acc[r].y, acc[r + 1].x, acc[r + 1].y};
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if (kt + r < n_out) y[kt + r] = acc[r];
+    }
+}
+
+// Variant 1: one tile per workgroup; latency hiding by occupancy alone.
 template <int T, int D, int R, int NT>
 __global__ __launch_bounds__(NT) void fe_fir_kernel(const uint8_t *__restrict__ x, const uint8_t *__restrict__ hist,
                                                      long n_bytes, const float *__restrict__ table,
@@ -86,21 +199,10 @@ __global__ __launch_bounds__(NT) void fe_fir_kernel(const uint8_t *__restrict__ 
 
     // ---- stage the tile's raw bytes: coalesced 16 B per lane ----
     constexpr int NCHUNK = C::TILE_BYTES / 16;
-    const u4 silence = {0u, 0u, 0u, 0u};  // u8 128 == 0.0f == signed byte 0
-    const uint32_t flip = 0x80808080u;    // u ^ 0x80 = (u - 128) as int8
 #pragma unroll
     for (int c0i = 0; c0i < NCHUNK; c0i += NT) {
         const int c = c0i + t;
-        if (c < NCHUNK) {
-            const long g = wbyte0 + 16L * c;
-            u4 v = silence;
-            if (g >= 0) {
-                if (g + 16 <= n_bytes) v = *reinterpret_cast<const u4 *>(x + g) ^ flip;
-            } else if (hist) {
-                v = *reinterpret_cast<const u4 *>(hist + (g + C::HB)) ^ flip;
-            }
-            lds[c] = v;
-        }
+        if (c < NCHUNK) lds[c] = fe_fetch<C::HB>(x, hist, n_bytes, wbyte0 + 16L * c);
     }
     __syncthreads();
 
@@ -119,65 +221,75 @@ __global__ __launch_bounds__(NT) void fe_fir_kernel(const uint8_t *__restrict__ 
     f2 acc[R];
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = (f2){0.0f, 0.0f};
+    fe_compute<T, D, R, NT>(raw, table, acc);
+    fe_store<R>(y, k0 + static_cast<long>(t) * R, n_out, acc);
+}
 
+// Variant 2: persistent workgroups; the NEXT tile's bytes are fetched into
+// registers while this tile's FMAs run, so HBM latency sits under VALU work
+// instead of in front of a barrier.
+template <int T, int D, int R, int NT>
+__global__ __launch_bounds__(NT) void fe_fir_kernel_pf(const uint8_t *__restrict__ x, const uint8_t *__restrict__ hist,
+                                                        long n_bytes, const float *__restrict__ table,
+                                                        f2 *__restrict__ y, long n_out, long n_tiles)
+{
+    using C = FeCfg<T, D, R, NT>;
+    extern __shared__ u4 lds[];
+    const int t = threadIdx.x;
+    constexpr int NCHUNK = C::TILE_BYTES / 16;
+    constexpr int NPF = (NCHUNK + NT - 1) / NT;  // 16-byte chunks each thread carries
+
+    u4 pre[NPF];
+    long tile = blockIdx.x;
+    if (tile < n_tiles) {
+        const long wbyte0 = 2L * D * tile * C::NOUT - C::HB;
 #pragma unroll
-    for (int p = 0; p < D; p++) {
-#pragma unroll
-        for (int c = 0; c < C::NC; c++) {
-            // taps of branch p, group c: wave-uniform, straight into SGPRs.  Inline
-            // asm keeps the loads HERE (hipcc otherwise hoists every tap load to the
-            // kernel entry and spills SGPRs); the wait is part of the statement.
-            f8 ha;
-            f4 hb;
-            asm volatile("s_load_dwordx8 %0, %2, %3\n\ts_load_dwordx4 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&s"(ha), "=&s"(hb)
-                         : "s"(table), "i"((p * C::NC + c) * kQC * 4), "i"((p * C::NC + c) * kQC * 4 + 32));
-            const float hq[kQC] = {ha[0], ha[1], ha[2], ha[3], ha[4], ha[5], ha[6], ha[7], hb[0], hb[1], hb[2], hb[3]};
-            // window samples j = p + D*i that meet taps q in [c*kQC, (c+1)*kQC)
-#pragma unroll
-            for (int ii = 0; ii < R + kQC - 1; ii++) {
-                const int i = c * kQC + ii;
-                const int j = p + D * i;
-                if (j < C::W) {
-                    const int bo = 2 * (j + C::LEAD);
-                    const uint32_t w = raw[bo / 4];
-                    f2 xs;
-                    // v_cvt_f32_i32_sdwa sext(w) src0_sel:BYTE_n
-                    if ((bo % 4) == 0) {
-                        xs.x = static_cast<float>(static_cast<int8_t>(w & 0xffu));
-                        xs.y = static_cast<float>(static_cast<int8_t>((w >> 8) & 0xffu));
-                    } else {
-                        xs.x = static_cast<float>(static_cast<int8_t>((w >> 16) & 0xffu));
-                        xs.y = static_cast<float>(static_cast<int8_t>(w >> 24));
-                    }
-#pragma unroll
-                    for (int r = 0; r < R; r++) {
-                        const int q = i - r;
-                        if (q >= c * kQC && q < (c + 1) * kQC && p + D * q < T) {
-                            const float h = hq[q - c * kQC];
-                            acc[r] = __builtin_elementwise_fma(xs, (f2){h, h}, acc[r]);  // v_pk_fma_f32
-                        }
-                    }
-                }
-            }
-            // pin this group's FMAs before the next group's tap loads (keeps the
-            // live set at one branch: ~110 VGPRs, 32 SGPRs, 4 waves/SIMD)
-#pragma unroll
-            for (int r = 0; r < R; r++) asm volatile("" : "+v"(acc[r]));
+        for (int k = 0; k < NPF; k++) {
+            const int c = k * NT + t;
+            pre[k] = (c < NCHUNK) ? fe_fetch<C::HB>(x, hist, n_bytes, wbyte0 + 16L * c) : (u4){0u, 0u, 0u, 0u};
         }
     }
-
-    // ---- R consecutive (I,Q) outputs per thread ----
-    const long kt = k0 + static_cast<long>(t) * R;
-    if (kt + R <= n_out) {
-        f4 *dst = reinterpret_cast<f4 *>(y + kt);
+    for (; tile < n_tiles; tile += gridDim.x) {
 #pragma unroll
-        for (int r = 0; r < R; r += 2) dst[r / 2] = (f4){acc[r].x, acc[r].y, acc[r + 1].x, acc[r + 1].y};
-    } else {
+        for (int k = 0; k < NPF; k++) {
+            const int c = k * NT + t;
+            if (c < NCHUNK) lds[c] = pre[k];
+        }
+        __syncthreads();
+        const u4 *lw = reinterpret_cast<const u4 *>(reinterpret_cast<const uint8_t *>(lds) + t * C::TSTRIDE);
+        uint32_t raw[C::NB * 4];
 #pragma unroll
-        for (int r = 0; r < R; r++)
-            if (kt + r < n_out) y[kt + r] = acc[r];
+        for (int i = 0; i < C::NB; i++) {
+            const u4 v = lw[i];
+            raw[4 * i] = v.x;
+            raw[4 * i + 1] = v.y;
+            raw[4 * i + 2] = v.z;
+            raw[4 * i + 3] = v.w;
+        }
+        __syncthreads();  // every window is in registers: the LDS tile may be overwritten
+        const long next = tile + gridDim.x;
+        if (next < n_tiles) {
+            const long wbyte0 = 2L * D * next * C::NOUT - C::HB;
+#pragma unroll
+            for (int k = 0; k < NPF; k++) {
+                const int c = k * NT + t;
+                if (c < NCHUNK) pre[k] = fe_fetch<C::HB>(x, hist, n_bytes, wbyte0 + 16L * c);
+            }
+        }
+        f2 acc[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = (f2){0.0f, 0.0f};
+        fe_compute<T, D, R, NT>(raw, table, acc);
+        fe_store<R>(y, tile * C::NOUT + static_cast<long>(t) * R, n_out, acc);
     }
+}
+
+// 1 = one tile per workgroup, 2 = persistent + register prefetch (default).
+// Read per launch so one process can A/B the two (tools/fe_ab.py).
+int fe_variant()
+{
+    const char *e = std::getenv("FMRX_FE_VARIANT");
+    return e ? std::atoi(e) : 2;
 }
 
 template <int T, int D>
@@ -187,9 +299,19 @@ int launch_fast(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const u
     constexpr int R = 8, NT = 256;
     using C = FeCfg<T, D, R, NT>;
     const long n_out = static_cast<long>(n_samples / D);
-    const unsigned grid = static_cast<unsigned>((n_out + C::NOUT - 1) / C::NOUT);
-    hipLaunchKernelGGL((fe_fir_kernel<T, D, R, NT>), dim3(grid), dim3(NT), C::TILE_BYTES, stream, d_iq, d_hist,
-                       static_cast<long>(2 * n_samples), pl.table.p, reinterpret_cast<f2 *>(d_if), n_out);
+    const long n_tiles = (n_out + C::NOUT - 1) / C::NOUT;
+    if (fe_variant() == 1) {
+        hipLaunchKernelGGL((fe_fir_kernel<T, D, R, NT>), dim3(static_cast<unsigned>(n_tiles)), dim3(NT), C::TILE_BYTES,
+                           stream, d_iq, d_hist, static_cast<long>(2 * n_samples), pl.table.p,
+                           reinterpret_cast<f2 *>(d_if), n_out);
+    } else {
+        // persistent: as many workgroups as fit at once (LDS allows 160 KiB / tile per CU)
+        const long per_cu = (160 * 1024) / C::TILE_BYTES > 8 ? 8 : (160 * 1024) / C::TILE_BYTES;
+        const long resident = 256 * (per_cu > 0 ? per_cu : 1);
+        const unsigned grid = static_cast<unsigned>(n_tiles < resident ? n_tiles : resident);
+        hipLaunchKernelGGL((fe_fir_kernel_pf<T, D, R, NT>), dim3(grid), dim3(NT), C::TILE_BYTES, stream, d_iq, d_hist,
+                           static_cast<long>(2 * n_samples), pl.table.p, reinterpret_cast<f2 *>(d_if), n_out, n_tiles);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FMRX_EHIP, "launch fe_fir_kernel<%d,%d>: %s", T, D, hipGetErrorString(e));
     return FMRX_OK;

@@ -11,6 +11,7 @@
 // kernels_audio.hip.
 //
 // Reference semantics: src/filter.cpp (line ranges cited per kernel).
+#include "device_math.hpp"
 #include "fmrx_internal.hpp"
 
 // No implicit a*b+c -> fma anywhere in this file: the reference is built for
@@ -107,16 +108,9 @@ __global__ void resample_generic_kernel(const float *__restrict__ x, size_t n_ou
 }
 
 // ---- FM discriminator (src/filter.cpp:248-266) ------------------------------------
-__device__ inline float demod_one(float i, float q, float pi, float pq)
-{
-    const float ii = i * i, qq = q * q;
-    const float den = ii + qq;
-    if (den == 0.0f) return 0.0f;
-    const float a = i * (q - pq);
-    const float b = q * (i - pi);
-    return (a - b) / den;  // IEEE divide (no fast-math)
-}
+__device__ inline float demod_one(float i, float q, float pi, float pq) { return demod_exact(i, q, pi, pq); }
 
+template <bool FAST>
 __global__ void demod_if_kernel(const float2 *__restrict__ z, size_t n, const float2 *__restrict__ prev,
                                 float2 *__restrict__ prev_out, float *__restrict__ out)
 {
@@ -124,7 +118,7 @@ __global__ void demod_if_kernel(const float2 *__restrict__ z, size_t n, const fl
     if (k >= n) return;
     const float2 c = z[k];
     const float2 p = k ? z[k - 1] : *prev;
-    out[k] = demod_one(c.x, c.y, p.x, p.y);
+    out[k] = FAST ? demod_fast(c.x, c.y, p.x, p.y) : demod_exact(c.x, c.y, p.x, p.y);
     if (prev_out && k == n - 1) *prev_out = c;
 }
 
@@ -155,21 +149,7 @@ __global__ void deinterleave_kernel(const float2 *__restrict__ iq, size_t n, flo
 }
 
 // src/threadMonoOnly.cpp:185-191
-__device__ inline int16_t pcm_one(float a, int wrap)
-{
-    if (a != a) return 0;
-    const float s = a * 16384;
-    if (wrap) {
-        // x86 cvttss2si: out-of-range -> 0x80000000, then the low 16 bits
-        int v;
-        if (s >= 2147483648.0f || s < -2147483648.0f) v = static_cast<int>(0x80000000u);
-        else v = static_cast<int>(s);
-        return static_cast<int16_t>(static_cast<uint16_t>(static_cast<uint32_t>(v)));
-    }
-    if (s >= 32767.0f) return 32767;
-    if (s <= -32768.0f) return -32768;
-    return static_cast<int16_t>(s);
-}
+__device__ inline int16_t pcm_one(float a, int wrap) { return pcm_pack(a, wrap); }
 
 __global__ void pcm16_kernel(const float *__restrict__ a, size_t n, int16_t *__restrict__ out, int wrap)
 {
@@ -307,11 +287,18 @@ int k_resample_generic(const float *d_x, size_t n_in, const float *d_h, int taps
     return FMRX_OK;
 }
 
-int k_fm_demod_if(const float *d_if, size_t n, const float *d_prev, float *d_prev_out, float *d_demod, hipStream_t s)
+int k_fm_demod_if(const float *d_if, size_t n, const float *d_prev, float *d_prev_out, float *d_demod, int fast,
+                  hipStream_t s)
 {
     if (n == 0) return FMRX_OK;
-    hipLaunchKernelGGL(demod_if_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, reinterpret_cast<const float2 *>(d_if), n,
-                       reinterpret_cast<const float2 *>(d_prev), reinterpret_cast<float2 *>(d_prev_out), d_demod);
+    if (fast)
+        hipLaunchKernelGGL(demod_if_kernel<true>, dim3(grid_for(n)), dim3(kBlock), 0, s,
+                           reinterpret_cast<const float2 *>(d_if), n, reinterpret_cast<const float2 *>(d_prev),
+                           reinterpret_cast<float2 *>(d_prev_out), d_demod);
+    else
+        hipLaunchKernelGGL(demod_if_kernel<false>, dim3(grid_for(n)), dim3(kBlock), 0, s,
+                           reinterpret_cast<const float2 *>(d_if), n, reinterpret_cast<const float2 *>(d_prev),
+                           reinterpret_cast<float2 *>(d_prev_out), d_demod);
     FMRX_LAUNCH_CHECK("demod_if");
     return FMRX_OK;
 }

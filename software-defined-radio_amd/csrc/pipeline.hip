@@ -52,6 +52,8 @@ struct fmrx_pipeline {
     DevBuf<int16_t> out_pcm;
 
     size_t last_n_if = 0, last_n_audio = 0;
+    const float *last_mono = nullptr;   // where the last block's mono audio was written
+    bool demod_full = true;             // demod[0..n_if) of the last block is materialised
     // profiling: a ring of per-call event quadruples {start, after FE kernel,
     // after audio stage, end}, recorded on the caller's stream
     static constexpr int kRing = 128;
@@ -95,8 +97,11 @@ int audio_stage(fmrx_pipeline *pl, const float *d_x, size_t n_in, int delay, flo
     if (pl->resample)
         return k_resample_generic(d_x - delay, n_in, pl->h_audio_rs.p, pl->p.audio_taps, pl->p.audio_decim,
                                   pl->p.audio_upsamp, d_y, s);
-    return audio_fir_launch(pl->audio, d_x, n_in, delay, d_y, s, pl->force_generic);
+    return audio_fir_launch(pl->audio, d_x, n_in, delay, d_y, nullptr, 0, s, pl->force_generic);
 }
+
+// the fused mono path exists for integer-decimation modes with specialised audio taps
+bool mono_fused(const fmrx_pipeline *pl) { return pl->channels == 1 && !pl->resample && pl->audio.fast && !pl->force_generic; }
 
 int reset_state(fmrx_pipeline *pl)
 {
@@ -293,10 +298,34 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
                            static_cast<long>(n_bytes), hb, pl->fe_hist[pl->fe_cur ^ 1].p);
         pl->fe_cur ^= 1;
     }
-    FMRX_TRY(k_fm_demod_if(pl->ifb.p, n_if, pl->prev_iq[pl->prev_cur].p, pl->prev_iq[pl->prev_cur ^ 1].p, demod, s));
+    const float *prev = pl->prev_iq[pl->prev_cur].p;
+    float *prev_next = pl->prev_iq[pl->prev_cur ^ 1].p;
     pl->prev_cur ^= 1;
 
+    if (mono_fused(pl)) {
+        // ---- RF_MONO, fused: discriminator + audio FIR + PCM in one kernel (project.cpp:128, 346;
+        //      threadMonoOnly.cpp:185-191); demod itself is only materialised for the history tail ----
+        float *dst = d_audio_f32 ? d_audio_f32 : pl->mono.p;
+        FMRX_TRY(audio_demod_fir_launch(pl->audio, pl->ifb.p, prev, demod, n_if, 0, dst, d_pcm16, pcm_policy, s));
+        if (pl->profiling) FMRX_HIP(hipEventRecord(ev[2], s));
+        const size_t g0 = n_if > static_cast<size_t>(pl->Hd) ? n_if - pl->Hd : 0;
+        FMRX_TRY(k_fm_demod_if(pl->ifb.p + 2 * g0, n_if - g0, g0 ? pl->ifb.p + 2 * (g0 - 1) : prev, prev_next, demod + g0,
+                               1, s));
+        FMRX_TRY(carry_history(pl, pl->demod.p, pl->Hd, n_if, s));
+        pl->last_mono = dst;
+        pl->demod_full = false;
+        if (pl->profiling) {
+            FMRX_HIP(hipEventRecord(ev[3], s));
+            pl->calls++;
+        }
+        return FMRX_OK;
+    }
+
+    FMRX_TRY(k_fm_demod_if(pl->ifb.p, n_if, prev, prev_next, demod, 0, s));
+    pl->demod_full = true;
+
     float *out_l = pl->mono.p, *out_r = nullptr;
+    pl->last_mono = pl->mono.p;
     if (pl->channels == 1) {
         // ---- RF_MONO: project.cpp:344-357 ----
         FMRX_TRY(audio_stage(pl, demod, n_if, 0, pl->mono.p, s));
@@ -365,8 +394,16 @@ int fmrx_pipeline_read_tap(fmrx_pipeline *pl, int which, float *out, size_t *n)
     switch (which) {
     case FMRX_TAP_IF_I:
     case FMRX_TAP_IF_Q: cnt = n_if; break;
-    case FMRX_TAP_DEMOD: src = pl->demod.p + pl->Hd; cnt = n_if; break;
-    case FMRX_TAP_MONO: src = pl->mono.p; cnt = n_au; break;
+    case FMRX_TAP_DEMOD:
+        if (!pl->demod_full) {
+            // the fused mono path keeps only the history tail: rebuild the block's discriminator
+            // output from the IF samples (still resident) with the same arithmetic
+            FMRX_TRY(k_fm_demod_if(pl->ifb.p, n_if, pl->prev_iq[pl->prev_cur ^ 1].p, nullptr, pl->demod.p + pl->Hd, 1, nullptr));
+            FMRX_HIP(hipDeviceSynchronize());
+            pl->demod_full = true;
+        }
+        src = pl->demod.p + pl->Hd; cnt = n_if; break;
+    case FMRX_TAP_MONO: src = pl->last_mono ? pl->last_mono : pl->mono.p; cnt = n_au; break;
     case FMRX_TAP_CARRIER: if (st) { src = pl->carrier.p; cnt = n_if; } break;
     case FMRX_TAP_STEREO_BPF: if (st) { src = pl->bpf.p; cnt = n_if; } break;
     case FMRX_TAP_PLL: if (st) { src = pl->pll.p; cnt = n_if + 1; } break;

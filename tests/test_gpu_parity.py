@@ -301,8 +301,9 @@ def test_real_signal_block(fmrx, oracle):
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_stereo_pipeline(fmrx, oracle, mode):
     """RF_STEREO.  Everything up to the PLL input is held to the mono tolerances;
-    PLL / mixer / L / R inherit the device-libm recurrence: 2e-3 absolute on the
-    NCO (it is O(1)), audio L/R RMS error <= 1e-3 of full scale."""
+    the NCO inherits the device-libm recurrence: 5e-3 absolute (measured <= 1e-3:
+    one float32 ulp of trigArg, which grows to ~1e4 rad, doubled by ncoScale);
+    audio L/R RMS error <= 1e-4 (measured 3e-6 .. 6e-6)."""
     iq = np.load(os.path.join(G, "synth_inputs.npz"))[f"mode{mode}"]
     g = np.load(os.path.join(G, f"synth_mode{mode}_ch2.npz"))
     bb, nblk = int(g["block_bytes"][0]), int(g["nblk"][0])
@@ -318,13 +319,13 @@ def test_stereo_pipeline(fmrx, oracle, mode):
         assert len(pll) == len(po.intermediate("pll"))
         pll_err = np.abs(pll - po.intermediate("pll")).max()
         print(f"mode {mode} block {b}: pll max err {pll_err:.2e}")
-        assert pll_err <= 2e-2
+        assert pll_err <= 5e-3
         for k in ("audio_l", "audio_r"):
             err = rms(out[k].astype(np.float64) - ref[k])
             print(f"mode {mode} block {b}: {k} rms err {err:.2e} (signal rms {rms(ref[k]):.3f})")
-            assert err <= 1e-3, (k, err)
+            assert err <= AUDIO_ABS_RMS, (k, err)
             err_g = rms(out[k].astype(np.float64) - g[f"b{b}_{k}"])
-            assert err_g <= 1e-3
+            assert err_g <= AUDIO_ABS_RMS
         # interleaved L,R PCM layout (project.cpp:292-302)
         assert len(out["pcm16"]) == 2 * len(out["audio_l"])
         assert_pcm_close(out["pcm16"][0::2], fmrx.pcm16(out["audio_l"]))

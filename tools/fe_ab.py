@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""A/B the front-end kernel variants in ONE process, interleaved rounds
+(cdna_hip_programming.md rule 24), on the bench workload's input.
+    python tools/fe_ab.py [blocks=256] [rounds=5]
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+fmrx = importlib.import_module("software-defined-radio_amd")
+synth = importlib.import_module("software-defined-radio_amd.synth")
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+N = 1_024_000
+iq = torch.from_numpy(synth.synth_fm_u8(4 * N)).cuda().repeat(B // 4)
+n = iq.numel() // 2
+h = fmrx.impulseResponseLPF(2.4e6, 100e3, 101)
+plan = fmrx.FrontEndPlan(h, 10)
+d_if = torch.empty(2 * (n // 10), dtype=torch.float32, device="cuda")
+hist = torch.full((plan.history_bytes,), 128, dtype=torch.uint8, device="cuda")
+s = torch.cuda.current_stream().cuda_stream
+res = {}
+outs = {}
+for rnd in range(ROUNDS):
+    for v in ("1", "2"):
+        os.environ["FMRX_FE_VARIANT"] = v
+        for _ in range(3):
+            plan.run_dev(iq.data_ptr(), n, hist.data_ptr(), d_if.data_ptr(), stream=s)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            plan.run_dev(iq.data_ptr(), n, hist.data_ptr(), d_if.data_ptr(), stream=s)
+        e1.record()
+        torch.cuda.synchronize()
+        res.setdefault(v, []).append(e0.elapsed_time(e1) / 10)
+        outs[v] = d_if.clone()
+assert torch.equal(outs["1"], outs["2"]), "variants disagree"
+for v, ts in res.items():
+    ms = float(np.median(ts))
+    print(f"variant {v}: median {ms:.4f} ms  min {min(ts):.4f}  -> {n / ms / 1e3:.0f} MS/s, "
+          f"{2.8 * n / ms / 1e6:.0f} GB/s algorithmic = {2.8 * n / ms / 1e6 / 8000:.3f} of HBM peak, "
+          f"{40.4 * n / ms / 1e9:.1f} TFLOP/s")
