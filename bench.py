@@ -38,10 +38,11 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 BLOCK_SAMPLES = 1_024_000          # complex samples per block (= 20 reference blocks)
 HBM_PEAK_GBS = 8000.0              # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-# algorithmic HBM bytes per complex input sample of the front-end kernel (S1,
-# SURVEY 8d): 2 B of u8 I/Q in + 8/rf_decim B of float I,Q out
-FE_BYTES_PER_SAMPLE = 2.0 + 8.0 / 10.0
-FE_FLOP_PER_SAMPLE = 2 * 2 * 101 / 10.0
+# algorithmic HBM bytes per complex input sample of the dominant kernel = front
+# end + discriminator fused (S2): 2 B of u8 I/Q in + 4/rf_decim B of
+# float demod out.  (The IF-only kernel, S1, would be 2 + 8/10 = 2.8 B.)
+FE_BYTES_PER_SAMPLE = 2.0 + 4.0 / 10.0
+FE_FLOP_PER_SAMPLE = 2 * 2 * 101 / 10.0 + 9 / 10.0
 
 
 def cpu_baseline(seconds: float = 10.0) -> dict:
@@ -182,7 +183,8 @@ def main() -> int:
                 "realtime_channels_equiv": round(value / 2.4, 0),
             },
             "roofline": {
-                "kernel": "fe_fir_kernel<101,10,8,256> (u8 I/Q -> 101-tap FIR -> decimate 10 -> f32 I,Q)",
+                "kernel": "fe_demod_kernel<101,10,8> (u8 I/Q -> 101-tap FIR -> decimate 10 -> FM discriminator -> f32 demod)",
+                "algorithmic_bytes_per_sample": FE_BYTES_PER_SAMPLE,
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(fe_bytes), "avg_launch_ms": round(fe_ms, 4),

@@ -208,6 +208,10 @@ FMRX_API int fmrx_pipeline_last_timing(fmrx_pipeline *pl, float *t);
 FMRX_API int fmrx_pipeline_timing_sum(fmrx_pipeline *pl, float *t, int *count, int max_calls);
 /* enable (1) / disable (0) the per-stage HIP events behind last_timing */
 FMRX_API int fmrx_pipeline_set_profiling(fmrx_pipeline *pl, int on);
+/* The fused front end consumes the IF I/Q samples in registers and does not
+ * write them to memory.  on = 1 makes it also store them so that
+ * FMRX_TAP_IF_I / FMRX_TAP_IF_Q can be read (diagnostics; default 0). */
+FMRX_API int fmrx_pipeline_set_keep_intermediates(fmrx_pipeline *pl, int on);
 /* force the parameter-generic kernels (1) or allow the specialised ones (0) */
 FMRX_API int fmrx_pipeline_set_force_generic(fmrx_pipeline *pl, int on);
 

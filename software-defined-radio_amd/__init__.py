@@ -119,6 +119,7 @@ _sig("fmrx_pipeline_last_timing", [_vp, _f32p])
 _sig("fmrx_pipeline_timing_sum", [_vp, _f32p, C.POINTER(_int), _int])
 _sig("fmrx_pipeline_set_profiling", [_vp, _int])
 _sig("fmrx_pipeline_set_force_generic", [_vp, _int])
+_sig("fmrx_pipeline_set_keep_intermediates", [_vp, _int])
 _sig("fmrx_fe_fir_decim_u8", [_u8p, _sz, _f32p, _sz, _uint, _vp, _vp, _vp, _int])
 _sig("fmrx_fe_plan_create", [C.POINTER(_vp), _f32p, _sz, _uint])
 _sig("fmrx_fe_plan_destroy", [_vp])
@@ -323,7 +324,7 @@ class Pipeline:
         _check(lib.fmrx_pipeline_create(C.byref(self._h), C.byref(self.params), channels, self.max_block_bytes, device))
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:  # lib is None during interpreter shutdown
             lib.fmrx_pipeline_destroy(self._h)
             self._h = None
 
@@ -340,6 +341,10 @@ class Pipeline:
 
     def set_profiling(self, on=True):
         _check(lib.fmrx_pipeline_set_profiling(self._h, int(on)))
+
+    def set_keep_intermediates(self, on=True):
+        """Also store the IF I/Q stream (read_tap('if_i'/'if_q')); the fused front end skips it by default."""
+        _check(lib.fmrx_pipeline_set_keep_intermediates(self._h, int(on)))
 
     def set_force_generic(self, on=True):
         _check(lib.fmrx_pipeline_set_force_generic(self._h, int(on)))
@@ -402,7 +407,7 @@ class FrontEndPlan:
         _check(lib.fmrx_fe_plan_create(C.byref(self._h), h, len(h), decim))
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:
             lib.fmrx_fe_plan_destroy(self._h)
             self._h = None
 

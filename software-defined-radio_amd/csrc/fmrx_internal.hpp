@@ -79,7 +79,13 @@ int fe_plan_init(FePlan &pl, const float *h, int taps, int decim);
 // Writes n_samples/decim float2 (I,Q) to d_if.
 int fe_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist, float *d_if,
               hipStream_t stream, bool force_generic);
-int fe_hist_bytes(int taps);
+int fe_hist_bytes(int taps, int decim);
+// Fused front end + discriminator (the pipeline's kernel).  d_demod[n/decim] is
+// written; d_if (interleaved I,Q) and d_prev_out (float2 = IF[n/decim-1]) are
+// optional; d_prev_override (float2) replaces the recomputed IF[-1] when given.
+bool fe_fused_available(const FePlan &pl, const uint8_t *d_iq, size_t n_samples);
+int fe_demod_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist,
+                    const float *d_prev_override, float *d_demod, float *d_if, float *d_prev_out, hipStream_t stream);
 
 // ---- audio fast path (kernels_audio.hip) --------------------------------------
 struct AudioPlan {
@@ -90,16 +96,11 @@ struct AudioPlan {
 };
 int audio_plan_init(AudioPlan &pl, const float *h, int taps, int decim);
 // y[k] = sum_n h[n] * x[decim*k - n - delay]; x points at the block start and
-// x[-(taps-1+delay) .. -1] must be readable history.
+// x[-(taps-1+delay+3) .. -1] must be readable history (the specialised kernel
+// loads 16-byte chunks).
 // Optionally also writes s16 PCM (d_pcm != nullptr).
 int audio_fir_launch(const AudioPlan &pl, const float *d_x, size_t n_in, int delay, float *d_y, int16_t *d_pcm, int wrap,
                      hipStream_t stream, bool force_generic);
-// Fused discriminator + audio FIR (+ PCM) straight from the IF I/Q pairs: d_if
-// = interleaved IF block, d_prev = IF[-1] (float2), d_demod_blk = pointer to
-// where demod[0] of this block lives (demod history at negative indices).
-// Only for plans with fast == true.
-int audio_demod_fir_launch(const AudioPlan &pl, const float *d_if, const float *d_prev, const float *d_demod_blk,
-                           size_t n_if, int delay, float *d_y, int16_t *d_pcm, int wrap, hipStream_t stream);
 
 // ---- generic kernels (kernels_generic.hip) ----------------------------------
 // y[k] = sum_{n<taps} h[n]*x[decim*k - n], sequential mul+add in n (bit-compatible

@@ -1,28 +1,23 @@
-// kernels_audio.hip -- the audio-rate stage: FM discriminator fused into the
-// decimating low-pass FIR, plus s16 packing, one kernel.
+// kernels_audio.hip -- the audio-rate stage: decimating low-pass FIR on the
+// FM-demodulated stream plus s16 packing, one kernel.
 //
-// Replaces fmDemod (src/project.cpp:128 -> src/filter.cpp:248-266), the audio
-// convolveBlockFastFIR of RF_MONO / RF_STEREO (src/project.cpp:346, 219, 257 ->
-// src/filter.cpp:158-188) and the PCM conversion (src/threadMonoOnly.cpp:185-191).
+// Replaces the audio convolveBlockFastFIR of RF_MONO / RF_STEREO
+// (src/project.cpp:346, 219, 257 -> src/filter.cpp:158-188) and the PCM
+// conversion (src/threadMonoOnly.cpp:185-191).
 //
-// Same register-window / packed-FMA structure as kernels_fe.hip, with two
+// Same register-blocked packed-FMA structure as kernels_fe.hip, with two
 // changes forced by the data: (1) the input is one real stream, so the two
 // halves of v_pk_fma_f32 carry two OUTPUTS that are HALF = NT*R apart (the tile
-// is split into a low and a high half and staged in LDS as (lo, hi) float
-// pairs); (2) float windows are too big for registers (136 samples x 2), so the
-// tile is staged PHASE-MAJOR -- LDS[p][i] = pair of sample p + D*i -- and a
-// thread streams one polyphase branch at a time: R+ceil(T/D)-1 consecutive
-// pairs (ds_read_b128, chunk-padded so lanes 64 B apart do not share a bank).
+// is split into a low and a high half, staged in LDS as (lo, hi) float pairs);
+// (2) float windows are too big for registers (136 samples x 2), so the tile
+// is staged PHASE-MAJOR -- LDS[p][i] = pair of sample p + D*i -- and a thread
+// streams one polyphase branch at a time: R+ceil(T/D)-1 consecutive pairs
+// (ds_read_b128, chunk-padded so lanes 64 B apart do not share a bank).
+// Staging reads the stream with coalesced 16-byte loads; samples before the
+// block come from the history kept in front of it (negative indices).
 //
-// Staging computes the discriminator on the fly from the IF I/Q pairs the
-// front end wrote (SRC_IF), so the demodulated stream is never written to or
-// read back from HBM in the mono path; samples before the block come from the
-// carried demod history.  SRC_FLOAT stages a plain float stream (the stereo
-// mixer output) through the same code.
-//
-// Numerics: one FMA per tap in polyphase order (as the front end); the
-// discriminator uses demod_fast (device_math.hpp).  The generic kernels keep
-// the reference's exact order and serve as the bit-compatible path.
+// Numerics: one FMA per tap in polyphase order.  The generic kernel keeps the
+// reference's exact order and serves as the bit-compatible path.
 #include "device_math.hpp"
 #include "fmrx_internal.hpp"
 
@@ -35,7 +30,6 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f8 __attribute__((ext_vector_type(8)));
 
 constexpr int kQC = 12;
-enum { SRC_IF = 0, SRC_FLOAT = 1 };
 
 template <int T, int D, int R, int NT>
 struct AuCfg {
@@ -56,9 +50,8 @@ struct AuCfg {
     static_assert(LDS_BYTES <= 64 * 1024, "tile exceeds the default LDS limit");
 };
 
-template <int T, int D, int R, int NT, int SRC>
-__global__ __launch_bounds__(NT) void audio_fir_kernel(const float2 *__restrict__ z, const float2 *__restrict__ prev,
-                                                        const float *__restrict__ xh, long n_in, int delay,
+template <int T, int D, int R, int NT>
+__global__ __launch_bounds__(NT) void audio_fir_kernel(const float *__restrict__ xh, long n_in, int delay,
                                                         const float *__restrict__ table, float *__restrict__ y,
                                                         int16_t *__restrict__ pcm, int wrap, long n_out)
 {
@@ -69,26 +62,33 @@ __global__ __launch_bounds__(NT) void audio_fir_kernel(const float2 *__restrict_
     const long a0 = static_cast<long>(blockIdx.x) * (2 * C::HALF);   // first output of the low half
     const long gbase = D * a0 - (T - 1) - delay;                      // input index of window sample 0 (low half)
 
-    // ---- stage both half-windows, phase-major, computing the discriminator on the way ----
-#pragma unroll 4
-    for (int jj = t; jj < 2 * C::WL; jj += NT) {
-        const int half = jj >= C::WL ? 1 : 0;
-        const int j = jj - half * C::WL;
-        const long g = gbase + static_cast<long>(half) * (D * C::HALF) + j;
-        float v = 0.0f;
-        if (g < 0) {
-            v = xh[g];  // carried history sits in front of the block
-        } else if (g < n_in) {
-            if (SRC == SRC_IF) {
-                const float2 c = z[g];
-                const float2 pz = g ? z[g - 1] : *prev;
-                v = demod_fast(c.x, c.y, pz.x, pz.y);
-            } else {
-                v = xh[g];
+    // ---- stage both half-windows phase-major: 16-byte loads, 4 samples per lane per step.
+    // xh is 16-byte aligned at index 0, so chunks start at multiples of 4 (also for
+    // negative indices = history); `off` = where the window starts inside its first chunk.
+    const long gal = gbase & ~3L;
+    const int off = static_cast<int>(gbase - gal);
+    constexpr int NCH4 = (C::WL + 3) / 4 + 1;
+    for (int cc = t; cc < 2 * NCH4; cc += NT) {
+        const int half = cc >= NCH4 ? 1 : 0;
+        const int c = cc - half * NCH4;
+        const long g0 = gal + static_cast<long>(half) * (D * C::HALF) + 4L * c;
+        f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (g0 < n_in) v = *reinterpret_cast<const f4 *>(xh + g0);
+        int j = 4 * c - off;                 // window index of v.x
+        int p = (j + 4 * D) % D;             // j >= -3, keep the operand non-negative
+        int i = (j + 4 * D) / D - 4;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const float val = (g0 + e < n_in) ? v[e] : 0.0f;
+            if (j >= 0 && j < C::WL)
+                *reinterpret_cast<float *>(ldsb + p * C::PH_BYTES + (i / R) * C::CHB + (i % R) * 8 + half * 4) = val;
+            j++;
+            p++;
+            if (p == D) {
+                p = 0;
+                i++;
             }
         }
-        const int p = j % D, i = j / D;
-        *reinterpret_cast<float *>(ldsb + p * C::PH_BYTES + (i / R) * C::CHB + (i % R) * 8 + half * 4) = v;
     }
     __syncthreads();
 
@@ -147,16 +147,15 @@ __global__ __launch_bounds__(NT) void audio_fir_kernel(const float2 *__restrict_
     }
 }
 
-template <int T, int D, int SRC>
-int launch_fast(const AudioPlan &pl, const float *d_if, const float *d_prev, const float *d_x, size_t n_in, int delay,
-                float *d_y, int16_t *d_pcm, int wrap, hipStream_t stream)
+template <int T, int D>
+int launch_fast(const AudioPlan &pl, const float *d_x, size_t n_in, int delay, float *d_y, int16_t *d_pcm, int wrap,
+                hipStream_t stream)
 {
     constexpr int R = 8, NT = 128;
     using C = AuCfg<T, D, R, NT>;
     const long n_out = static_cast<long>(n_in / D);
     const unsigned grid = static_cast<unsigned>((n_out + 2 * C::HALF - 1) / (2 * C::HALF));
-    hipLaunchKernelGGL((audio_fir_kernel<T, D, R, NT, SRC>), dim3(grid), dim3(NT), C::LDS_BYTES, stream,
-                       reinterpret_cast<const float2 *>(d_if), reinterpret_cast<const float2 *>(d_prev), d_x,
+    hipLaunchKernelGGL((audio_fir_kernel<T, D, R, NT>), dim3(grid), dim3(NT), C::LDS_BYTES, stream, d_x,
                        static_cast<long>(n_in), delay, pl.table.p, d_y, d_pcm, wrap, n_out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FMRX_EHIP, "launch audio_fir_kernel<%d,%d>: %s", T, D, hipGetErrorString(e));
@@ -207,28 +206,16 @@ int audio_fir_launch(const AudioPlan &pl, const float *d_x, size_t n_in, int del
                      hipStream_t stream, bool force_generic)
 {
     if (n_in / pl.decim == 0) return FMRX_OK;
-    if (pl.fast && !force_generic) {
+    // the specialised kernel reads 16-byte chunks relative to d_x: d_x must be 16-byte aligned
+    if (pl.fast && !force_generic && reinterpret_cast<uintptr_t>(d_x) % 16 == 0) {
 #define X(T_, D_) \
-    if (pl.taps == T_ && pl.decim == D_) \
-        return launch_fast<T_, D_, SRC_FLOAT>(pl, nullptr, nullptr, d_x, n_in, delay, d_y, d_pcm, wrap, stream);
+    if (pl.taps == T_ && pl.decim == D_) return launch_fast<T_, D_>(pl, d_x, n_in, delay, d_y, d_pcm, wrap, stream);
         FMRX_AUDIO_CASES(X)
 #undef X
     }
     FMRX_TRY(k_fir_generic(d_x - delay, n_in / pl.decim, pl.h.p, pl.taps, pl.decim, d_y, stream));
     if (d_pcm) FMRX_TRY(k_pcm16(d_y, n_in / pl.decim, d_pcm, wrap, stream));
     return FMRX_OK;
-}
-
-int audio_demod_fir_launch(const AudioPlan &pl, const float *d_if, const float *d_prev, const float *d_demod_blk,
-                           size_t n_if, int delay, float *d_y, int16_t *d_pcm, int wrap, hipStream_t stream)
-{
-    if (n_if / pl.decim == 0) return FMRX_OK;
-#define X(T_, D_) \
-    if (pl.taps == T_ && pl.decim == D_) \
-        return launch_fast<T_, D_, SRC_IF>(pl, d_if, d_prev, d_demod_blk, n_if, delay, d_y, d_pcm, wrap, stream);
-    FMRX_AUDIO_CASES(X)
-#undef X
-    return fail(FMRX_EINVAL, "audio_demod_fir_launch: no specialised kernel for taps=%d decim=%d", pl.taps, pl.decim);
 }
 
 }  // namespace fmrx

@@ -40,6 +40,7 @@
 // instead of n = 0..T-1; the result differs from the reference's sequential
 // multiply/add by a few float32 ulp (tests bound the RMS error; the pipeline's
 // audio stays within 1e-4 RMS of the reference, SURVEY 7.3 "Summation order").
+#include "device_math.hpp"
 #include "fmrx_internal.hpp"
 
 namespace fmrx {
@@ -284,6 +285,174 @@ __global__ __launch_bounds__(NT) void fe_fir_kernel_pf(const uint8_t *__restrict
     }
 }
 
+// Variant 3 (the pipeline's kernel): front end + FM discriminator fused, one
+// WAVE per tile.  Adds to variant 2:
+//  * wave-private tiles: each of the workgroup's 4 waves stages, reads and
+//    computes its own 64-thread tile in its own LDS region, so there is no
+//    workgroup barrier anywhere -- a wave never waits for another wave;
+//  * the discriminator (src/filter.cpp:248-266) runs in the epilogue on the IF
+//    samples still in registers.  Output k needs IF[k-1]: inside a thread that
+//    is the previous accumulator, across threads one lane shift (ds_bpermute).
+//    Lane 0 of every tile exists only to supply IF[k-1] to lane 1: tiles overlap
+//    by R outputs (1/64 redundant work) and every IF sample is produced by the
+//    same instruction sequence wherever it is computed, so results do not depend
+//    on how the stream is cut into tiles or blocks;
+//  * the IF stream itself is written only on request (d_if != nullptr): the mono
+//    and stereo chains consume demod, which costs 4/D bytes per input sample
+//    instead of 8/D.
+template <int T, int D, int R>
+struct FeWaveCfg {
+    using C = FeCfg<T, D, R, 64>;
+    static constexpr int STRIDE = 63 * R;                      // new outputs per wave tile
+    static constexpr int NCHUNK = C::TILE_BYTES / 16;          // 16-byte chunks of one wave tile
+    static constexpr int NPF = (NCHUNK + 63) / 64;             // LDS-DMA instructions per tile (1 KiB each)
+    static constexpr int WREGION = NPF * 1024;                 // LDS bytes per wave
+    static constexpr int HBX = C::HB + 2 * D * R;              // history bytes in front of a block (lane 0 of tile 0)
+    static constexpr int MINW = ((160 * 1024) / (4 * WREGION) >= 3 && T <= 101) ? 3 : 2;   // waves per SIMD to compile for
+    static_assert(HBX % 16 == 0, "alignment");
+};
+
+__device__ const u4 g_silence = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};  // u8 128 = 0.0f
+
+// source address of one 16-byte chunk of a tile window: block bytes, carried
+// history, or the silence constant beyond either end
+template <int HB>
+__device__ __forceinline__ const uint8_t *fe_src(const uint8_t *__restrict__ x, const uint8_t *__restrict__ hist, long n_bytes,
+                                                 long g, bool in_tile)
+{
+    const uint8_t *p = reinterpret_cast<const uint8_t *>(&g_silence);
+    if (in_tile) {
+        if (g >= 0) {
+            if (g + 16 <= n_bytes) p = x + g;
+        } else if (hist) {
+            p = hist + (g + HB);
+        }
+    }
+    return p;
+}
+
+// stage one wave tile: NPF LDS-DMA instructions, 64 lanes x 16 B each, no VGPR
+// destination -- the bytes land in the wave's LDS region while the wave computes
+template <int T, int D, int R>
+__device__ __forceinline__ void fe_dma_tile(const uint8_t *__restrict__ x, const uint8_t *__restrict__ hist, long n_bytes,
+                                            long w, u4 *wl, int lane)
+{
+    using W = FeWaveCfg<T, D, R>;
+    const long wbyte0 = 2L * D * (w * W::STRIDE - R) - W::C::HB;
+#pragma unroll
+    for (int k = 0; k < W::NPF; k++) {
+        const int c = k * 64 + lane;
+        const uint8_t *src = fe_src<W::HBX>(x, hist, n_bytes, wbyte0 + 16L * c, c < W::NCHUNK);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(wl + k * 64), 16, 0, 0);
+    }
+}
+
+template <int T, int D, int R>
+__global__ __launch_bounds__(256, (FeWaveCfg<T, D, R>::MINW)) void fe_demod_kernel(
+    const uint8_t *__restrict__ x, const uint8_t *__restrict__ hist, long n_bytes, const float *__restrict__ table,
+    const float2 *__restrict__ prev_override, float *__restrict__ demod, f2 *__restrict__ y_if,
+    float2 *__restrict__ prev_out, long n_out, long n_wtiles)
+{
+    using W = FeWaveCfg<T, D, R>;
+    using C = typename W::C;
+    extern __shared__ u4 lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    u4 *wl = lds + wave * (W::WREGION / 16);                   // this wave's private region
+    const long n_waves = static_cast<long>(gridDim.x) * 4;
+    long w = static_cast<long>(blockIdx.x) * 4 + wave;
+    const uint32_t flip = 0x80808080u;                         // u ^ 0x80 = (u - 128) as int8
+
+    if (w < n_wtiles) fe_dma_tile<T, D, R>(x, hist, n_bytes, w, wl, lane);
+    for (; w < n_wtiles; w += n_waves) {
+        // the tile's bytes (and this wave's older stores) have landed
+        __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const u4 *lw = reinterpret_cast<const u4 *>(reinterpret_cast<const uint8_t *>(wl) + lane * C::TSTRIDE);
+        uint32_t raw[C::NB * 4];
+#pragma unroll
+        for (int i = 0; i < C::NB; i++) {
+            const u4 v = lw[i];
+            raw[4 * i] = v.x ^ flip;
+            raw[4 * i + 1] = v.y ^ flip;
+            raw[4 * i + 2] = v.z ^ flip;
+            raw[4 * i + 3] = v.w ^ flip;
+        }
+        // every lane's window is in registers before the region is overwritten
+        __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const long next = w + n_waves;
+        if (next < n_wtiles) fe_dma_tile<T, D, R>(x, hist, n_bytes, next, wl, lane);
+
+        f2 acc[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = (f2){0.0f, 0.0f};
+        fe_compute<T, D, R, 64>(raw, table, acc);
+
+        // ---- discriminator on the register-resident IF samples ----
+        const long kt = w * W::STRIDE + static_cast<long>(lane - 1) * R;   // first output of this lane (lane 0: previous tile's)
+        float pi = __shfl_up(acc[R - 1].x, 1, 64), pq = __shfl_up(acc[R - 1].y, 1, 64);
+        if (prev_override && kt == 0) {
+            const float2 po = *prev_override;
+            pi = po.x;
+            pq = po.y;
+        }
+        float d[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            d[r] = demod_fast(acc[r].x, acc[r].y, pi, pq);
+            pi = acc[r].x;
+            pq = acc[r].y;
+        }
+        if (lane > 0 && kt < n_out) {
+            if (kt + R <= n_out) {
+                f4 *dd = reinterpret_cast<f4 *>(demod + kt);
+#pragma unroll
+                for (int r = 0; r < R; r += 4) dd[r / 4] = (f4){d[r], d[r + 1], d[r + 2], d[r + 3]};
+                if (y_if) {
+                    f4 *dst = reinterpret_cast<f4 *>(y_if + kt);
+#pragma unroll
+                    for (int r = 0; r < R; r += 2) dst[r / 2] = (f4){acc[r].x, acc[r].y, acc[r + 1].x, acc[r + 1].y};
+                }
+                if (prev_out && kt + R == n_out) *prev_out = make_float2(acc[R - 1].x, acc[R - 1].y);
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; r++)
+                    if (kt + r < n_out) {
+                        demod[kt + r] = d[r];
+                        if (y_if) y_if[kt + r] = acc[r];
+                        if (prev_out && kt + r == n_out - 1) *prev_out = make_float2(acc[r].x, acc[r].y);
+                    }
+            }
+        }
+    }
+}
+
+template <int T, int D>
+int launch_fused(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist, const float *d_prev_override,
+                 float *d_demod, float *d_if, float *d_prev_out, hipStream_t stream)
+{
+    constexpr int R = 8;
+    using W = FeWaveCfg<T, D, R>;
+    const long n_out = static_cast<long>(n_samples / D);
+    const long n_wtiles = (n_out + W::STRIDE - 1) / W::STRIDE;
+    const long lds_wg = 4L * W::WREGION;
+    long per_cu = (160 * 1024) / lds_wg;
+    if (per_cu > 4) per_cu = 4;
+    if (per_cu < 1) per_cu = 1;
+    const long want = (n_wtiles + 3) / 4;
+    const unsigned grid = static_cast<unsigned>(want < 256 * per_cu ? want : 256 * per_cu);
+    hipLaunchKernelGGL((fe_demod_kernel<T, D, R>), dim3(grid), dim3(256), static_cast<size_t>(lds_wg), stream, d_iq, d_hist,
+                       static_cast<long>(2 * n_samples), pl.table.p, reinterpret_cast<const float2 *>(d_prev_override),
+                       d_demod, reinterpret_cast<f2 *>(d_if), reinterpret_cast<float2 *>(d_prev_out), n_out, n_wtiles);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FMRX_EHIP, "launch fe_demod_kernel<%d,%d>: %s", T, D, hipGetErrorString(e));
+    return FMRX_OK;
+}
+
 // 1 = one tile per workgroup, 2 = persistent + register prefetch (default).
 // Read per launch so one process can A/B the two (tools/fe_ab.py).
 int fe_variant()
@@ -335,17 +504,20 @@ void build_table(const float *h, std::vector<float> &tab)
 
 }  // namespace
 
-int fe_hist_bytes(int taps)
+// bytes of history kept in front of a block: the taps-1 samples the FIR needs,
+// rounded up to 16 bytes, plus decim*8 samples so that the fused kernel's lane 0
+// can recompute the previous block's last IF samples (a multiple of 16 bytes)
+int fe_hist_bytes(int taps, int decim)
 {
     const int lead = (8 - (taps - 1) % 8) % 8;
-    return 2 * (taps - 1 + lead);
+    return 2 * (taps - 1 + lead) + 2 * decim * 8;
 }
 
 int fe_plan_init(FePlan &pl, const float *h, int taps, int decim)
 {
     pl.taps = taps;
     pl.decim = decim;
-    pl.hist_bytes = fe_hist_bytes(taps);
+    pl.hist_bytes = fe_hist_bytes(taps, decim);
     pl.fast = false;
     FMRX_TRY(pl.h.alloc(taps));
     FMRX_HIP(hipMemcpy(pl.h.p, h, taps * sizeof(float), hipMemcpyHostToDevice));
@@ -371,12 +543,31 @@ int fe_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uin
     const bool aligned = (reinterpret_cast<uintptr_t>(d_iq) % 16 == 0) && ((2 * n_samples) % 16 == 0) &&
                          (!d_hist || reinterpret_cast<uintptr_t>(d_hist) % 16 == 0);
     if (pl.fast && aligned && !force_generic) {
+        // the IF-only kernels read just the last 2*(taps-1+lead) bytes of the history
+        const uint8_t *h1 = d_hist ? d_hist + 2 * pl.decim * 8 : nullptr;
 #define X(T_, D_) \
-    if (pl.taps == T_ && pl.decim == D_) return launch_fast<T_, D_>(pl, d_iq, n_samples, d_hist, d_if, stream);
+    if (pl.taps == T_ && pl.decim == D_) return launch_fast<T_, D_>(pl, d_iq, n_samples, h1, d_if, stream);
         FMRX_FE_CASES(X)
 #undef X
     }
     return k_fe_generic(d_iq, d_hist, pl.hist_bytes, n_samples, pl.h.p, pl.taps, pl.decim, d_if, stream);
+}
+
+bool fe_fused_available(const FePlan &pl, const uint8_t *d_iq, size_t n_samples)
+{
+    return pl.fast && (reinterpret_cast<uintptr_t>(d_iq) % 16 == 0) && ((2 * n_samples) % 16 == 0);
+}
+
+int fe_demod_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist,
+                    const float *d_prev_override, float *d_demod, float *d_if, float *d_prev_out, hipStream_t stream)
+{
+    if (n_samples / pl.decim == 0) return FMRX_OK;
+#define X(T_, D_) \
+    if (pl.taps == T_ && pl.decim == D_) \
+        return launch_fused<T_, D_>(pl, d_iq, n_samples, d_hist, d_prev_override, d_demod, d_if, d_prev_out, stream);
+    FMRX_FE_CASES(X)
+#undef X
+    return fail(FMRX_EINVAL, "fe_demod_launch: no specialised kernel for taps=%d decim=%d", pl.taps, pl.decim);
 }
 
 }  // namespace fmrx

@@ -32,8 +32,12 @@ struct fmrx_pipeline {
     bool profiling = false;
     int Ha = 0;     // audio-stage history, in its input samples
     int delay = 0;  // all-pass delay (stereo), samples
-    int Hd = 0;     // history kept in front of demod
+    int Hd = 0;     // history kept in front of demod (>= what the stages need, multiple of 4: keeps demod[0] 16-byte aligned)
+    int Hm = 0;     // history kept in front of the stereo mixer output (same rule)
     int St = 0;     // stereo taps
+    bool keep_if = false;        // materialise the IF I/Q stream (diagnostics / read_tap)
+    bool prev_override = false;  // the next block takes IF[-1] from prev_iq (after set_state)
+    bool if_valid = false;       // ifb holds the last block's IF samples
 
     hipStream_t stream = nullptr;  // used by the host-buffer entry point
     FePlan fe;
@@ -53,7 +57,6 @@ struct fmrx_pipeline {
 
     size_t last_n_if = 0, last_n_audio = 0;
     const float *last_mono = nullptr;   // where the last block's mono audio was written
-    bool demod_full = true;             // demod[0..n_if) of the last block is materialised
     // profiling: a ring of per-call event quadruples {start, after FE kernel,
     // after audio stage, end}, recorded on the caller's stream
     static constexpr int kRing = 128;
@@ -100,8 +103,6 @@ int audio_stage(fmrx_pipeline *pl, const float *d_x, size_t n_in, int delay, flo
     return audio_fir_launch(pl->audio, d_x, n_in, delay, d_y, nullptr, 0, s, pl->force_generic);
 }
 
-// the fused mono path exists for integer-decimation modes with specialised audio taps
-bool mono_fused(const fmrx_pipeline *pl) { return pl->channels == 1 && !pl->resample && pl->audio.fast && !pl->force_generic; }
 
 int reset_state(fmrx_pipeline *pl)
 {
@@ -112,12 +113,14 @@ int reset_state(fmrx_pipeline *pl)
     }
     FMRX_HIP(hipMemsetAsync(pl->demod.p, 0, pl->Hd * sizeof(float), s));
     if (pl->channels == 2) {
-        FMRX_HIP(hipMemsetAsync(pl->mixer.p, 0, pl->Ha * sizeof(float), s));
+        FMRX_HIP(hipMemsetAsync(pl->mixer.p, 0, pl->Hm * sizeof(float), s));
         const float init[6] = {0.0f, 0.0f, 1.0f, 0.0f, 1.0f, 0.0f};  // src/project.cpp:458
         FMRX_HIP(hipMemcpyAsync(pl->pll_state.p, init, sizeof(init), hipMemcpyHostToDevice, s));
     }
     FMRX_HIP(hipStreamSynchronize(s));
     pl->fe_cur = pl->prev_cur = 0;
+    pl->prev_override = false;
+    pl->if_valid = false;
     return FMRX_OK;
 }
 
@@ -170,6 +173,8 @@ int fmrx_pipeline_create(fmrx_pipeline **out, const fmrx_params *p, int channels
     pl->delay = channels == 2 ? (p->stereo_taps - 1) / 2 : 0;
     pl->Hd = pl->Ha + pl->delay;
     if (channels == 2 && pl->St - 1 > pl->Hd) pl->Hd = pl->St - 1;
+    pl->Hd = (pl->Hd + 3) / 4 * 4 + 4;   // the specialised audio kernel loads aligned 16-byte chunks
+    pl->Hm = (pl->Ha + 3) / 4 * 4 + 4;
 
     int rc = FMRX_OK;
     auto body = [&]() -> int {
@@ -199,7 +204,7 @@ int fmrx_pipeline_create(fmrx_pipeline **out, const fmrx_params *p, int channels
         }
         FMRX_TRY(pl->ifb.alloc(2 * n_if + 16));
         FMRX_TRY(pl->demod.alloc(pl->Hd + n_if + 16));
-        FMRX_TRY(pl->tmp_hist.alloc(pl->Hd + pl->Ha + 16));
+        FMRX_TRY(pl->tmp_hist.alloc(pl->Hd + pl->Hm + 16));
         FMRX_TRY(pl->mono.alloc(n_au));
         if (channels == 2) {
             h.resize(p->stereo_taps);
@@ -213,7 +218,7 @@ int fmrx_pipeline_create(fmrx_pipeline **out, const fmrx_params *p, int channels
             FMRX_TRY(pl->bpf.alloc(n_if + 16));
             FMRX_TRY(pl->pll.alloc(n_if + 17));
             FMRX_TRY(pl->pll_state.alloc(8));
-            FMRX_TRY(pl->mixer.alloc(pl->Ha + n_if + 16));
+            FMRX_TRY(pl->mixer.alloc(pl->Hm + n_if + 16));
             FMRX_TRY(pl->st_final.alloc(n_au));
             FMRX_TRY(pl->left.alloc(n_au));
             FMRX_TRY(pl->right.alloc(n_au));
@@ -264,6 +269,13 @@ int fmrx_pipeline_set_profiling(fmrx_pipeline *pl, int on)
     return FMRX_OK;
 }
 
+int fmrx_pipeline_set_keep_intermediates(fmrx_pipeline *pl, int on)
+{
+    if (!pl) return fail(FMRX_EINVAL, "null handle");
+    pl->keep_if = on != 0;
+    return FMRX_OK;
+}
+
 int fmrx_pipeline_set_force_generic(fmrx_pipeline *pl, int on)
 {
     if (!pl) return fail(FMRX_EINVAL, "null handle");
@@ -288,32 +300,38 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
     hipEvent_t *ev = pl->ev[pl->calls % fmrx_pipeline::kRing];
     if (pl->profiling) FMRX_HIP(hipEventRecord(ev[0], s));
 
-    // ---- RF_FrontEnd: project.cpp:82-128 ----
+    // ---- RF_FrontEnd: project.cpp:82-128 (u8 -> IF I/Q -> discriminator) ----
     const uint8_t *hist = pl->fe_hist[pl->fe_cur].p;
-    FMRX_TRY(fe_launch(pl->fe, d_iq, n, hist, pl->ifb.p, s, pl->force_generic));
+    const float *prev = pl->prev_iq[pl->prev_cur].p;
+    float *prev_next = pl->prev_iq[pl->prev_cur ^ 1].p;
+    if (!pl->force_generic && fe_fused_available(pl->fe, d_iq, n)) {
+        // one kernel; the IF stream is written only when somebody asked to look at it
+        FMRX_TRY(fe_demod_launch(pl->fe, d_iq, n, hist, pl->prev_override ? prev : nullptr, demod,
+                                 pl->keep_if ? pl->ifb.p : nullptr, prev_next, s));
+        pl->if_valid = pl->keep_if;
+    } else {
+        FMRX_TRY(fe_launch(pl->fe, d_iq, n, hist, pl->ifb.p, s, pl->force_generic));
+        FMRX_TRY(k_fm_demod_if(pl->ifb.p, n_if, prev, prev_next, demod, 0, s));
+        pl->if_valid = true;
+    }
+    pl->prev_cur ^= 1;
+    pl->prev_override = false;
     if (pl->profiling) FMRX_HIP(hipEventRecord(ev[1], s));
-    {   // I_state/Q_state <- last rf_taps-1 samples (filter.cpp:182-187), as raw bytes
+    {   // I_state/Q_state <- last samples of the block (filter.cpp:182-187), kept as raw bytes
         const int hb = pl->fe.hist_bytes;
         hipLaunchKernelGGL(hist_update_kernel, dim3((hb + 255) / 256), dim3(256), 0, s, hist, d_iq,
                            static_cast<long>(n_bytes), hb, pl->fe_hist[pl->fe_cur ^ 1].p);
         pl->fe_cur ^= 1;
     }
-    const float *prev = pl->prev_iq[pl->prev_cur].p;
-    float *prev_next = pl->prev_iq[pl->prev_cur ^ 1].p;
-    pl->prev_cur ^= 1;
 
-    if (mono_fused(pl)) {
-        // ---- RF_MONO, fused: discriminator + audio FIR + PCM in one kernel (project.cpp:128, 346;
-        //      threadMonoOnly.cpp:185-191); demod itself is only materialised for the history tail ----
+    if (pl->channels == 1 && !pl->resample) {
+        // ---- RF_MONO, modes 0/1: audio FIR + decimate + PCM in one kernel (project.cpp:346;
+        //      threadMonoOnly.cpp:185-191), straight into the caller's buffers ----
         float *dst = d_audio_f32 ? d_audio_f32 : pl->mono.p;
-        FMRX_TRY(audio_demod_fir_launch(pl->audio, pl->ifb.p, prev, demod, n_if, 0, dst, d_pcm16, pcm_policy, s));
-        if (pl->profiling) FMRX_HIP(hipEventRecord(ev[2], s));
-        const size_t g0 = n_if > static_cast<size_t>(pl->Hd) ? n_if - pl->Hd : 0;
-        FMRX_TRY(k_fm_demod_if(pl->ifb.p + 2 * g0, n_if - g0, g0 ? pl->ifb.p + 2 * (g0 - 1) : prev, prev_next, demod + g0,
-                               1, s));
-        FMRX_TRY(carry_history(pl, pl->demod.p, pl->Hd, n_if, s));
+        FMRX_TRY(audio_fir_launch(pl->audio, demod, n_if, 0, dst, d_pcm16, pcm_policy, s, pl->force_generic));
         pl->last_mono = dst;
-        pl->demod_full = false;
+        if (pl->profiling) FMRX_HIP(hipEventRecord(ev[2], s));
+        FMRX_TRY(carry_history(pl, pl->demod.p, pl->Hd, n_if, s));
         if (pl->profiling) {
             FMRX_HIP(hipEventRecord(ev[3], s));
             pl->calls++;
@@ -321,18 +339,15 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
         return FMRX_OK;
     }
 
-    FMRX_TRY(k_fm_demod_if(pl->ifb.p, n_if, prev, prev_next, demod, 0, s));
-    pl->demod_full = true;
-
     float *out_l = pl->mono.p, *out_r = nullptr;
     pl->last_mono = pl->mono.p;
     if (pl->channels == 1) {
-        // ---- RF_MONO: project.cpp:344-357 ----
+        // ---- RF_MONO, modes 2/3: rational resampler (project.cpp:353) ----
         FMRX_TRY(audio_stage(pl, demod, n_if, 0, pl->mono.p, s));
         if (pl->profiling) FMRX_HIP(hipEventRecord(ev[2], s));
     } else {
         // ---- RF_STEREO: project.cpp:194-280 ----
-        float *mixer = pl->mixer.p + pl->Ha;
+        float *mixer = pl->mixer.p + pl->Hm;
         FMRX_TRY(audio_stage(pl, demod, n_if, pl->delay, pl->mono.p, s));  // all-pass = index offset
         if (pl->profiling) FMRX_HIP(hipEventRecord(ev[2], s));
         FMRX_TRY(k_fir_generic(demod, n_if, pl->h_stereo.p, pl->St, 1, pl->bpf.p, s));
@@ -342,7 +357,7 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
         FMRX_TRY(k_mix(pl->bpf.p, pl->pll.p, n_if, mixer, s));
         FMRX_TRY(audio_stage(pl, mixer, n_if, 0, pl->st_final.p, s));
         FMRX_TRY(k_combine(pl->st_final.p, pl->mono.p, n_au, pl->left.p, pl->right.p, s));
-        FMRX_TRY(carry_history(pl, pl->mixer.p, pl->Ha, n_if, s));
+        FMRX_TRY(carry_history(pl, pl->mixer.p, pl->Hm, n_if, s));
         out_l = pl->left.p;
         out_r = pl->right.p;
     }
@@ -395,25 +410,25 @@ int fmrx_pipeline_read_tap(fmrx_pipeline *pl, int which, float *out, size_t *n)
     case FMRX_TAP_IF_I:
     case FMRX_TAP_IF_Q: cnt = n_if; break;
     case FMRX_TAP_DEMOD:
-        if (!pl->demod_full) {
-            // the fused mono path keeps only the history tail: rebuild the block's discriminator
-            // output from the IF samples (still resident) with the same arithmetic
-            FMRX_TRY(k_fm_demod_if(pl->ifb.p, n_if, pl->prev_iq[pl->prev_cur ^ 1].p, nullptr, pl->demod.p + pl->Hd, 1, nullptr));
-            FMRX_HIP(hipDeviceSynchronize());
-            pl->demod_full = true;
-        }
+        // the block was shifted into the history position by carry_history: it is the
+        // last n_if samples of [Hd | n_if] only until the next block; read it from the
+        // tail copy kept in front when the block is shorter than that -- simplest: the
+        // block region itself is still intact (carry copies, it does not move)
         src = pl->demod.p + pl->Hd; cnt = n_if; break;
     case FMRX_TAP_MONO: src = pl->last_mono ? pl->last_mono : pl->mono.p; cnt = n_au; break;
     case FMRX_TAP_CARRIER: if (st) { src = pl->carrier.p; cnt = n_if; } break;
     case FMRX_TAP_STEREO_BPF: if (st) { src = pl->bpf.p; cnt = n_if; } break;
     case FMRX_TAP_PLL: if (st) { src = pl->pll.p; cnt = n_if + 1; } break;
-    case FMRX_TAP_MIXER: if (st) { src = pl->mixer.p + pl->Ha; cnt = n_if; } break;
+    case FMRX_TAP_MIXER: if (st) { src = pl->mixer.p + pl->Hm; cnt = n_if; } break;
     case FMRX_TAP_STEREO_FINAL: if (st) { src = pl->st_final.p; cnt = n_au; } break;
     default: return fail(FMRX_EINVAL, "read_tap: unknown tap %d", which);
     }
     if (which >= FMRX_TAP_CARRIER && !st) return fail(FMRX_EINVAL, "read_tap: tap %d exists only in stereo pipelines", which);
     *n = cnt;
     if (!out || cnt == 0) return FMRX_OK;
+    if ((which == FMRX_TAP_IF_I || which == FMRX_TAP_IF_Q) && !pl->if_valid)
+        return fail(FMRX_EINVAL, "read_tap: the IF stream is not materialised by the fused front end; call "
+                                 "fmrx_pipeline_set_keep_intermediates(pl, 1) before processing");
     if (which == FMRX_TAP_IF_I || which == FMRX_TAP_IF_Q) {
         // NOTE: demod of the block already shifted the history; IF is intact
         std::vector<float> z(2 * cnt);
@@ -459,7 +474,7 @@ int fmrx_pipeline_get_state(fmrx_pipeline *pl, float *state, size_t n)
     if (pl->channels == 2) {
         std::memcpy(o, dend - (pl->St - 1), (pl->St - 1) * sizeof(float)); o += pl->St - 1;  // state_stereo
         std::memcpy(o, dend - (pl->St - 1), (pl->St - 1) * sizeof(float)); o += pl->St - 1;  // state_carrier
-        FMRX_HIP(hipMemcpy(o, pl->mixer.p, pl->Ha * sizeof(float), hipMemcpyDeviceToHost)); o += pl->Ha;  // state_stereofilt
+        FMRX_HIP(hipMemcpy(o, pl->mixer.p + (pl->Hm - pl->Ha), pl->Ha * sizeof(float), hipMemcpyDeviceToHost)); o += pl->Ha;  // state_stereofilt
         std::memcpy(o, dend - pl->delay, pl->delay * sizeof(float)); o += pl->delay;        // state_allpass
         FMRX_HIP(hipMemcpy(o, pl->pll_state.p, 6 * sizeof(float), hipMemcpyDeviceToHost)); o += 6;
     }
@@ -498,13 +513,15 @@ int fmrx_pipeline_set_state(fmrx_pipeline *pl, const float *state, size_t n)
         std::memcpy(dend - pl->delay, s_ap, pl->delay * sizeof(float));
         std::memcpy(dend - (pl->St - 1), s_st, (pl->St - 1) * sizeof(float));
         (void)s_car;  // identical to state_stereo by construction (same input stream)
-        FMRX_HIP(hipMemcpy(pl->mixer.p, s_sf, pl->Ha * sizeof(float), hipMemcpyHostToDevice));
+        FMRX_HIP(hipMemset(pl->mixer.p, 0, pl->Hm * sizeof(float)));
+        FMRX_HIP(hipMemcpy(pl->mixer.p + (pl->Hm - pl->Ha), s_sf, pl->Ha * sizeof(float), hipMemcpyHostToDevice));
         FMRX_HIP(hipMemcpy(pl->pll_state.p, o, 6 * sizeof(float), hipMemcpyHostToDevice));
         o += 6;
     } else {
         std::memcpy(dend - pl->Ha, s_mono, pl->Ha * sizeof(float));
     }
     FMRX_HIP(hipMemcpy(pl->demod.p, dh.data(), pl->Hd * sizeof(float), hipMemcpyHostToDevice));
+    pl->prev_override = true;   // the fused front end would otherwise recompute IF[-1] from the byte history
     return FMRX_OK;
 }
 

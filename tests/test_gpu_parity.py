@@ -242,6 +242,7 @@ def test_mono_pipeline_vs_golden_and_oracle(fmrx, oracle, mode):
     g = np.load(os.path.join(G, f"synth_mode{mode}_ch1.npz"))
     bb, nblk = int(g["block_bytes"][0]), int(g["nblk"][0])
     pl = fmrx.Pipeline(mode, 1)
+    pl.set_keep_intermediates(True)     # the fused front end does not store IF I/Q unless asked
     po = oracle.pipeline(mode, 1)
     for b in range(nblk):
         blk = iq[b * bb:(b + 1) * bb]
@@ -289,6 +290,9 @@ def test_real_signal_block(fmrx, oracle):
     for rf_t, au_t in [(101, 101), (151, 101), (13, 13)]:
         tag = f"t{rf_t}_{au_t}"
         pl = fmrx.Pipeline(0, 1, rf_taps=rf_t, base_audio_taps=au_t)
+        with pytest.raises(fmrx.FmrxError):   # IF is not materialised unless asked for
+            pl.process(iq); pl.read_tap("if_i")
+        pl.reset(); pl.set_keep_intermediates(True)
         out = pl.process(iq)
         assert rel_rms(pl.read_tap("if_i"), g[f"{tag}_if_i"]) <= FE_REL_RMS
         # spikes come from |z| ~ 0 samples: error is amplified there, bound it relative to signal RMS
