@@ -21,15 +21,17 @@ __device__ __forceinline__ float demod_exact(float i, float q, float pi, float p
     return __fdiv_rn(__fsub_rn(a, b), den);
 }
 
-// Throughput form used by the specialised pipeline: FMAs and a 1-ulp hardware
-// reciprocal (v_rcp_f32) instead of the ~10-instruction IEEE divide.  Same
-// den == 0 -> 0 rule; |error| <= ~2 ulp of the quotient.  Tiny denominators
-// (where v_rcp_f32 would leave the normal range) take the exact path.
+// Throughput form used by the specialised pipeline: the reference's numerator
+// and denominator (separately rounded products -- so degenerate cases such as
+// I*Q - Q*I stay exactly 0, which the stereo PLL's atan2 is sensitive to), but
+// a 1-ulp hardware reciprocal (v_rcp_f32) instead of the ~10-instruction IEEE
+// divide: |error| <= ~1.5 ulp of the quotient.  Tiny denominators (where
+// v_rcp_f32 would leave the normal range) take the exact path.
 __device__ __forceinline__ float demod_fast(float i, float q, float pi, float pq)
 {
-    const float den = __fmaf_rn(q, q, __fmul_rn(i, i));
+    const float den = __fadd_rn(__fmul_rn(i, i), __fmul_rn(q, q));
     if (den == 0.0f) return 0.0f;
-    const float num = __fmaf_rn(i, __fsub_rn(q, pq), -__fmul_rn(q, __fsub_rn(i, pi)));
+    const float num = __fsub_rn(__fmul_rn(i, __fsub_rn(q, pq)), __fmul_rn(q, __fsub_rn(i, pi)));
     if (den < 1e-30f) return __fdiv_rn(num, den);
     return __fmul_rn(num, __builtin_amdgcn_rcpf(den));
 }

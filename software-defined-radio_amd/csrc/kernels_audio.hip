@@ -38,8 +38,9 @@ struct AuCfg {
     static constexpr int HALF = NT * R;                 // outputs per half tile
     static constexpr int WL = D * (HALF - 1) + T;       // input samples one half needs
     static constexpr int NI = HALF + QT - 1;            // pairs per polyphase branch
-    static constexpr int CHB = R * 8 + 16;              // bytes per padded chunk of R pairs
-    static constexpr int NCHK = NI / R + 1;               // +1: the last b128 of the last thread may touch pair NI
+    static constexpr int PAD = R >= 8 ? 16 : 0;         // R=8: lanes 64 B apart would be 4-way bank conflicts; R=4: 2-way, cheaper than the LDS
+    static constexpr int CHB = R * 8 + PAD;             // bytes per chunk of R pairs
+    static constexpr int NCHK = NI / R + 1;             // +1: the last b128 of the last thread may touch pair NI
     static constexpr int PH_BYTES = NCHK * CHB;
     static constexpr int LDS_BYTES = D * PH_BYTES;
     static constexpr int WT = D * (R - 1) + T;          // samples one thread's outputs span
@@ -68,25 +69,38 @@ __global__ __launch_bounds__(NT) void audio_fir_kernel(const float *__restrict__
     const long gal = gbase & ~3L;
     const int off = static_cast<int>(gbase - gal);
     constexpr int NCH4 = (C::WL + 3) / 4 + 1;
-    for (int cc = t; cc < 2 * NCH4; cc += NT) {
-        const int half = cc >= NCH4 ? 1 : 0;
-        const int c = cc - half * NCH4;
-        const long g0 = gal + static_cast<long>(half) * (D * C::HALF) + 4L * c;
-        f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (g0 < n_in) v = *reinterpret_cast<const f4 *>(xh + g0);
-        int j = 4 * c - off;                 // window index of v.x
-        int p = (j + 4 * D) % D;             // j >= -3, keep the operand non-negative
-        int i = (j + 4 * D) / D - 4;
+    constexpr int NIT = (2 * NCH4 + NT - 1) / NT;
+    f4 v[NIT];
+    // all of a thread's loads first (NIT independent 16-byte loads in flight), then the scatter
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const float val = (g0 + e < n_in) ? v[e] : 0.0f;
-            if (j >= 0 && j < C::WL)
-                *reinterpret_cast<float *>(ldsb + p * C::PH_BYTES + (i / R) * C::CHB + (i % R) * 8 + half * 4) = val;
-            j++;
-            p++;
-            if (p == D) {
-                p = 0;
-                i++;
+    for (int it = 0; it < NIT; it++) {
+        const int cc = t + it * NT;
+        const int half = cc >= NCH4 ? 1 : 0;
+        const long g0 = gal + static_cast<long>(half) * (D * C::HALF) + 4L * (cc - half * NCH4);
+        v[it] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+        if (cc < 2 * NCH4 && g0 < n_in) v[it] = *reinterpret_cast<const f4 *>(xh + g0);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int cc = t + it * NT;
+        if (cc < 2 * NCH4) {
+            const int half = cc >= NCH4 ? 1 : 0;
+            const int c = cc - half * NCH4;
+            const long g0 = gal + static_cast<long>(half) * (D * C::HALF) + 4L * c;
+            int j = 4 * c - off;                 // window index of v.x
+            int p = (j + 4 * D) % D;             // j >= -3, keep the operand non-negative
+            int i = (j + 4 * D) / D - 4;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float val = (g0 + e < n_in) ? v[it][e] : 0.0f;
+                if (j >= 0 && j < C::WL)
+                    *reinterpret_cast<float *>(ldsb + p * C::PH_BYTES + (i / R) * C::CHB + (i % R) * 8 + half * 4) = val;
+                j++;
+                p++;
+                if (p == D) {
+                    p = 0;
+                    i++;
+                }
             }
         }
     }
@@ -151,7 +165,7 @@ template <int T, int D>
 int launch_fast(const AudioPlan &pl, const float *d_x, size_t n_in, int delay, float *d_y, int16_t *d_pcm, int wrap,
                 hipStream_t stream)
 {
-    constexpr int R = 8, NT = 128;
+    constexpr int R = 4, NT = 256;
     using C = AuCfg<T, D, R, NT>;
     const long n_out = static_cast<long>(n_in / D);
     const unsigned grid = static_cast<unsigned>((n_out + 2 * C::HALF - 1) / (2 * C::HALF));
@@ -165,7 +179,7 @@ int launch_fast(const AudioPlan &pl, const float *d_x, size_t n_in, int delay, f
 template <int T, int D>
 void build_table(const float *h, std::vector<float> &tab)
 {
-    using C = AuCfg<T, D, 8, 128>;
+    using C = AuCfg<T, D, 4, 256>;
     tab.assign(C::TABLE, 0.0f);
     for (int p = 0; p < D; p++)
         for (int q = 0; q < C::NC * kQC; q++) {
