@@ -6,6 +6,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Plain operators below must stay separate IEEE operations: no a*b+c -> fma.
+// (The __fmul_rn/__fadd_rn intrinsics are not enough: they inline OCML bitcode
+// whose multiplies carry the `contract` flag and get fused anyway.)  Files that
+// want FMAs ask for them explicitly (__builtin_elementwise_fma / fmaf).
+#pragma clang fp contract(off)
+
 namespace fmrx {
 
 // FM discriminator, reference evaluation order (src/filter.cpp:254-259):
@@ -13,12 +19,12 @@ namespace fmrx {
 // with contraction off for this to stay bit-compatible.
 __device__ __forceinline__ float demod_exact(float i, float q, float pi, float pq)
 {
-    const float ii = __fmul_rn(i, i), qq = __fmul_rn(q, q);
-    const float den = __fadd_rn(ii, qq);
+    const float ii = i * i, qq = q * q;
+    const float den = ii + qq;
     if (den == 0.0f) return 0.0f;
-    const float a = __fmul_rn(i, __fsub_rn(q, pq));
-    const float b = __fmul_rn(q, __fsub_rn(i, pi));
-    return __fdiv_rn(__fsub_rn(a, b), den);
+    const float a = i * (q - pq);
+    const float b = q * (i - pi);
+    return (a - b) / den;  // IEEE divide
 }
 
 // Throughput form used by the specialised pipeline: the reference's numerator
@@ -29,11 +35,14 @@ __device__ __forceinline__ float demod_exact(float i, float q, float pi, float p
 // v_rcp_f32 would leave the normal range) take the exact path.
 __device__ __forceinline__ float demod_fast(float i, float q, float pi, float pq)
 {
-    const float den = __fadd_rn(__fmul_rn(i, i), __fmul_rn(q, q));
+    const float ii = i * i, qq = q * q;
+    const float den = ii + qq;
     if (den == 0.0f) return 0.0f;
-    const float num = __fsub_rn(__fmul_rn(i, __fsub_rn(q, pq)), __fmul_rn(q, __fsub_rn(i, pi)));
-    if (den < 1e-30f) return __fdiv_rn(num, den);
-    return __fmul_rn(num, __builtin_amdgcn_rcpf(den));
+    const float a = i * (q - pq);
+    const float b = q * (i - pi);
+    const float num = a - b;
+    if (den < 1e-30f) return num / den;
+    return num * __builtin_amdgcn_rcpf(den);
 }
 
 // PCM pack of src/threadMonoOnly.cpp:185-191: NaN -> 0 else (short)(a*16384).
@@ -41,7 +50,7 @@ __device__ __forceinline__ float demod_fast(float i, float q, float pi, float pq
 __device__ __forceinline__ int16_t pcm_pack(float a, int wrap)
 {
     if (a != a) return 0;
-    const float s = __fmul_rn(a, 16384.0f);
+    const float s = a * 16384.0f;
     if (wrap) {
         int v;
         if (s >= 2147483648.0f || s < -2147483648.0f) v = static_cast<int>(0x80000000u);

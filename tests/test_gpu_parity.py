@@ -321,9 +321,15 @@ def test_stereo_pipeline(fmrx, oracle, mode):
         assert_audio_close(pl.read_tap("mono_filt"), po.intermediate("mono_filt"), "mono branch (all-pass + FIR)")
         pll = pl.read_tap("pll")
         assert len(pll) == len(po.intermediate("pll"))
-        pll_err = np.abs(pll - po.intermediate("pll")).max()
-        print(f"mode {mode} block {b}: pll max err {pll_err:.2e}")
-        assert pll_err <= 5e-3
+        dp = np.abs(pll - po.intermediate("pll"))
+        first = int(np.argmax(dp > 5e-3)) if (dp > 5e-3).any() else -1
+        print(f"mode {mode} block {b}: pll max err {dp.max():.2e} (first 2000: {dp[:2000].max():.2e}, rest: "
+              f"{dp[2000:].max():.2e}, first index over 5e-3: {first}, rms {rms(dp):.2e})")
+        # fmPLL's phase detector is atan2(-c*sin, c*cos): only the SIGN of the pilot-band sample c
+        # matters, so a stream's first samples must be EXACT zeros where the reference's are (the
+        # discriminator keeps the reference's rounded-product order for that reason: an FMA there
+        # leaves a 1e-8 residual that kicks the loop by 5e-2).
+        assert dp.max() <= 5e-3
         for k in ("audio_l", "audio_r"):
             err = rms(out[k].astype(np.float64) - ref[k])
             print(f"mode {mode} block {b}: {k} rms err {err:.2e} (signal rms {rms(ref[k]):.3f})")
