@@ -87,6 +87,62 @@ def cpu_baseline(seconds: float = 10.0) -> dict:
     }
 
 
+def init_ranks(backend: str | None):
+    """One process per GPU (torch.distributed.run sets RANK/LOCAL_RANK/WORLD_SIZE).
+    Returns (rank, local_rank, world, dist-or-None).  The process group is CONTROL
+    PLANE only (barrier + max of the elapsed time): channels never exchange data."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return rank, local_rank, world, None
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend or "gloo", rank=rank, world_size=world)
+    return rank, local_rank, world, dist
+
+
+def channel_seed(rank: int) -> int:
+    """Channel c of the job = the synthetic stream with seed 0x3D74 + c."""
+    return 0x3D74 + rank
+
+
+def timed_region(step, sync, steps: int, warmup: int, dist, device=None) -> float:
+    """W untimed warm-up steps, then exactly K steps bracketed by barrier + device sync on both
+    sides; returns the MAX over ranks of the elapsed seconds."""
+    import torch
+
+    def barrier():
+        sync()
+        if dist is not None:
+            dist.barrier()
+        sync()
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device or "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    return elapsed
+
+
+def job_throughput(world: int, samples_per_step_per_rank: int, steps: int, elapsed_max: float) -> float:
+    """Whole-job MS/s: units all ranks processed / the slowest rank's time."""
+    return world * samples_per_step_per_rank * steps / elapsed_max / 1e6
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -99,18 +155,11 @@ def main() -> int:
 
     import torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         print(json.dumps({"error": "no GPU visible; libfmrx has no CPU fallback"}))
         return 2
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist  # control plane only: barrier + max of the elapsed time
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    rank, local_rank, world, dist = init_ranks("nccl")
 
     fmrx = importlib.import_module("software-defined-radio_amd")
     synth = importlib.import_module("software-defined-radio_amd.synth")
@@ -118,7 +167,7 @@ def main() -> int:
     # ---- device-resident synthetic stream: this rank's channel ----
     B = args.blocks
     base_blocks = 4 if B % 4 == 0 else 1
-    iq_host = synth.synth_fm_u8(BLOCK_SAMPLES * base_blocks, 2.4e6, seed=0x3D74 + rank)
+    iq_host = synth.synth_fm_u8(BLOCK_SAMPLES * base_blocks, 2.4e6, seed=channel_seed(rank))
     d_iq = torch.from_numpy(iq_host).cuda().repeat(B // base_blocks)       # [2 * B * 1,024,000] u8
     n_bytes = d_iq.numel()
     n_samples = n_bytes // 2
@@ -131,25 +180,10 @@ def main() -> int:
     def step():
         pl.process_dev(d_iq.data_ptr(), n_bytes, d_audio.data_ptr(), d_pcm.data_ptr(), wrap=True, stream=stream)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         step()
     pl.set_profiling(True)       # HIP events around the front-end kernel, on the launch stream
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = timed_region(step, torch.cuda.synchronize, args.steps, 0, dist, device="cuda")
 
     tsum, cnt = pl.timing_sum(args.steps)
     fe_ms = tsum["front_end_ms"] / cnt
@@ -157,8 +191,7 @@ def main() -> int:
 
     out = None
     if rank == 0:
-        total_samples = world * n_samples * args.steps
-        value = total_samples / elapsed / 1e6
+        value = job_throughput(world, n_samples, args.steps, elapsed)
         fe_bytes = FE_BYTES_PER_SAMPLE * n_samples
         achieved = fe_bytes / (fe_ms * 1e-3) / 1e9
         traffic = None
