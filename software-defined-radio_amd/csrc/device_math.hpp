@@ -31,8 +31,9 @@ __device__ __forceinline__ float demod_exact(float i, float q, float pi, float p
 // and denominator (separately rounded products -- so degenerate cases such as
 // I*Q - Q*I stay exactly 0, which the stereo PLL's atan2 is sensitive to), but
 // a 1-ulp hardware reciprocal (v_rcp_f32) instead of the ~10-instruction IEEE
-// divide: |error| <= ~1.5 ulp of the quotient.  Tiny denominators (where
-// v_rcp_f32 would leave the normal range) take the exact path.
+// divide: |error| <= ~1.5 ulp of the quotient.  Tiny denominators are scaled
+// by 2^64 first (numerator too: same quotient) so v_rcp_f32 never sees a
+// denormal or overflows; branch-free.
 __device__ __forceinline__ float demod_fast(float i, float q, float pi, float pq)
 {
     const float ii = i * i, qq = q * q;
@@ -41,8 +42,8 @@ __device__ __forceinline__ float demod_fast(float i, float q, float pi, float pq
     const float a = i * (q - pq);
     const float b = q * (i - pi);
     const float num = a - b;
-    if (den < 1e-30f) return num / den;
-    return num * __builtin_amdgcn_rcpf(den);
+    const float sc = den < 8.6736174e-19f ? 1.8446744e19f : 1.0f;   // den < 2^-60 ? 2^64 : 1
+    return (num * sc) * __builtin_amdgcn_rcpf(den * sc);
 }
 
 // PCM pack of src/threadMonoOnly.cpp:185-191: NaN -> 0 else (short)(a*16384).

@@ -332,19 +332,30 @@ __device__ __forceinline__ const uint8_t *fe_src(const uint8_t *__restrict__ x, 
 }
 
 // stage one wave tile: NPF LDS-DMA instructions, 64 lanes x 16 B each, no VGPR
-// destination -- the bytes land in the wave's LDS region while the wave computes
+// destination -- the bytes land in the wave's LDS region while the wave computes.
+// Interior tiles (every byte inside the block: all but the first and last few)
+// take a wave-uniform fast path: one scalar base, lane*16 + k*1024 offsets.
 template <int T, int D, int R>
 __device__ __forceinline__ void fe_dma_tile(const uint8_t *__restrict__ x, const uint8_t *__restrict__ hist, long n_bytes,
-                                            long w, u4 *wl, int lane)
+                                            int w, u4 *wl, int lane)
 {
     using W = FeWaveCfg<T, D, R>;
-    const long wbyte0 = 2L * D * (w * W::STRIDE - R) - W::C::HB;
+    const long wbyte0 = 2L * D * (static_cast<long>(w) * W::STRIDE - R) - W::C::HB;   // wave-uniform
+    if (wbyte0 >= 0 && wbyte0 + W::NPF * 1024L <= n_bytes) {
+        const uint8_t *base = x + wbyte0;               // scalar
+        const int loff = lane * 16;
 #pragma unroll
-    for (int k = 0; k < W::NPF; k++) {
-        const int c = k * 64 + lane;
-        const uint8_t *src = fe_src<W::HBX>(x, hist, n_bytes, wbyte0 + 16L * c, c < W::NCHUNK);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)(wl + k * 64), 16, 0, 0);
+        for (int k = 0; k < W::NPF; k++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + (loff + k * 1024)),
+                                             (__attribute__((address_space(3))) void *)(wl + k * 64), 16, 0, 0);
+    } else {
+#pragma unroll
+        for (int k = 0; k < W::NPF; k++) {
+            const int c = k * 64 + lane;
+            const uint8_t *src = fe_src<W::HBX>(x, hist, n_bytes, wbyte0 + 16L * c, c < W::NCHUNK);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(wl + k * 64), 16, 0, 0);
+        }
     }
 }
 
@@ -352,7 +363,7 @@ template <int T, int D, int R>
 __global__ __launch_bounds__(256, (FeWaveCfg<T, D, R>::MINW)) void fe_demod_kernel(
     const uint8_t *__restrict__ x, const uint8_t *__restrict__ hist, long n_bytes, const float *__restrict__ table,
     const float2 *__restrict__ prev_override, float *__restrict__ demod, f2 *__restrict__ y_if,
-    float2 *__restrict__ prev_out, long n_out, long n_wtiles)
+    float2 *__restrict__ prev_out, long n_out, int n_wtiles)
 {
     using W = FeWaveCfg<T, D, R>;
     using C = typename W::C;
@@ -360,8 +371,9 @@ __global__ __launch_bounds__(256, (FeWaveCfg<T, D, R>::MINW)) void fe_demod_kern
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     u4 *wl = lds + wave * (W::WREGION / 16);                   // this wave's private region
-    const long n_waves = static_cast<long>(gridDim.x) * 4;
-    long w = static_cast<long>(blockIdx.x) * 4 + wave;
+    const int n_waves = static_cast<int>(gridDim.x) * 4;
+    // tile index: the same in every lane; tell the compiler (scalar address math, uniform branches)
+    int w = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * 4 + wave);
     const uint32_t flip = 0x80808080u;                         // u ^ 0x80 = (u - 128) as int8
 
     if (w < n_wtiles) fe_dma_tile<T, D, R>(x, hist, n_bytes, w, wl, lane);
@@ -384,7 +396,7 @@ __global__ __launch_bounds__(256, (FeWaveCfg<T, D, R>::MINW)) void fe_demod_kern
         __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const long next = w + n_waves;
+        const int next = w + n_waves;
         if (next < n_wtiles) fe_dma_tile<T, D, R>(x, hist, n_bytes, next, wl, lane);
 
         f2 acc[R];
@@ -393,7 +405,7 @@ __global__ __launch_bounds__(256, (FeWaveCfg<T, D, R>::MINW)) void fe_demod_kern
         fe_compute<T, D, R, 64>(raw, table, acc);
 
         // ---- discriminator on the register-resident IF samples ----
-        const long kt = w * W::STRIDE + static_cast<long>(lane - 1) * R;   // first output of this lane (lane 0: previous tile's)
+        const long kt = static_cast<long>(w) * W::STRIDE + static_cast<long>(lane - 1) * R;   // first output of this lane (lane 0: previous tile's)
         float pi = __shfl_up(acc[R - 1].x, 1, 64), pq = __shfl_up(acc[R - 1].y, 1, 64);
         if (prev_override && kt == 0) {
             const float2 po = *prev_override;
@@ -447,7 +459,8 @@ int launch_fused(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const 
     const unsigned grid = static_cast<unsigned>(want < 256 * per_cu ? want : 256 * per_cu);
     hipLaunchKernelGGL((fe_demod_kernel<T, D, R>), dim3(grid), dim3(256), static_cast<size_t>(lds_wg), stream, d_iq, d_hist,
                        static_cast<long>(2 * n_samples), pl.table.p, reinterpret_cast<const float2 *>(d_prev_override),
-                       d_demod, reinterpret_cast<f2 *>(d_if), reinterpret_cast<float2 *>(d_prev_out), n_out, n_wtiles);
+                       d_demod, reinterpret_cast<f2 *>(d_if), reinterpret_cast<float2 *>(d_prev_out), n_out,
+                       static_cast<int>(n_wtiles));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FMRX_EHIP, "launch fe_demod_kernel<%d,%d>: %s", T, D, hipGetErrorString(e));
     return FMRX_OK;
