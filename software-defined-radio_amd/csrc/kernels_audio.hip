@@ -9,12 +9,14 @@
 // changes forced by the data: (1) the input is one real stream, so the two
 // halves of v_pk_fma_f32 carry two OUTPUTS that are HALF = NT*R apart (the tile
 // is split into a low and a high half, staged in LDS as (lo, hi) float pairs);
-// (2) float windows are too big for registers (136 samples x 2), so the tile
-// is staged PHASE-MAJOR -- LDS[p][i] = pair of sample p + D*i -- and a thread
-// streams one polyphase branch at a time: R+ceil(T/D)-1 consecutive pairs
-// (ds_read_b128, chunk-padded so lanes 64 B apart do not share a bank).
-// Staging reads the stream with coalesced 16-byte loads; samples before the
-// block come from the history kept in front of it (negative indices).
+// (2) float windows are too big for registers, so a thread streams one
+// polyphase branch at a time from LDS: the R+ceil(T/D)-1 pairs p + D*ii, one
+// ds_read_b64 each at a compile-time offset from the thread's base.  The tile
+// sits in LDS in stream order with one pad pair per R*D pairs, so lanes are
+// 8*(R*D+1) bytes apart and a wave's 64 reads hit 64 distinct banks.
+// Staging reads the stream with coalesced 16-byte loads (all of a thread's
+// loads in flight together); samples before the block come from the history
+// kept in front of it (negative indices).
 //
 // Numerics: one FMA per tap in polyphase order.  The generic kernel keeps the
 // reference's exact order and serves as the bit-compatible path.
@@ -31,25 +33,73 @@ typedef float f8 __attribute__((ext_vector_type(8)));
 
 constexpr int kQC = 12;
 
+#define FMRX_TAPS_ISSUE(ha, hb, table, off) \
+    asm volatile("s_load_dwordx8 %0, %2, %3\n\ts_load_dwordx4 %1, %2, %4" : "=&s"(ha), "=&s"(hb) : "s"(table), "i"(off), "i"((off) + 32))
+#define FMRX_TAPS_WAIT(ha, hb) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ha), "+s"(hb))
+
 template <int T, int D, int R, int NT>
 struct AuCfg {
     static constexpr int QT = (T + D - 1) / D;
     static constexpr int NC = (QT + kQC - 1) / kQC;
     static constexpr int HALF = NT * R;                 // outputs per half tile
     static constexpr int WL = D * (HALF - 1) + T;       // input samples one half needs
-    static constexpr int NI = HALF + QT - 1;            // pairs per polyphase branch
-    static constexpr int PAD = R >= 8 ? 16 : 0;         // R=8: lanes 64 B apart would be 4-way bank conflicts; R=4: 2-way, cheaper than the LDS
-    static constexpr int CHB = R * 8 + PAD;             // bytes per chunk of R pairs
-    static constexpr int NCHK = NI / R + 1;             // +1: the last b128 of the last thread may touch pair NI
-    static constexpr int PH_BYTES = NCHK * CHB;
-    static constexpr int LDS_BYTES = D * PH_BYTES;
+    static constexpr int PADP = R * D;                  // pairs between pad slots = one thread's stride
+    static constexpr int NSLOT = WL + WL / PADP + 2;    // pair slots incl. pads; the last one is a dump slot
+    static constexpr int LDS_BYTES = (NSLOT * 8 + 15) / 16 * 16;
     static constexpr int WT = D * (R - 1) + T;          // samples one thread's outputs span
     static constexpr int NPAIR = R + QT - 1;            // pairs a thread reads per branch
-    static constexpr int NRD = (NPAIR + 1) / 2;         // ds_read_b128 per branch
     static constexpr int TABLE = D * NC * kQC;
-    static_assert(R % 2 == 0, "pairs are read two at a time");
     static_assert(LDS_BYTES <= 64 * 1024, "tile exceeds the default LDS limit");
+    static_assert(WL < 65536, "staging uses a 16-bit reciprocal division");
 };
+
+// byte offset of window sample j's pair slot
+template <int PADP>
+__device__ __forceinline__ constexpr int au_slot(int j) { return (j + j / PADP) * 8; }
+
+template <int T, int D, int R, int NT, int G>
+__device__ __forceinline__ void au_step(const uint8_t *tb, const float *__restrict__ table, f2 (&acc)[R], f8 &haA, f4 &hbA,
+                                        f8 &haB, f4 &hbB)
+{
+    using C = AuCfg<T, D, R, NT>;
+    constexpr int NG = D * C::NC;
+    if constexpr (G < NG) {
+        constexpr int p = G / C::NC, c = G % C::NC;
+        float hq[kQC];
+        if constexpr (G % 2 == 0) {
+            FMRX_TAPS_WAIT(haA, hbA);
+            if constexpr (G + 1 < NG) FMRX_TAPS_ISSUE(haB, hbB, table, (G + 1) * kQC * 4);
+#pragma unroll
+            for (int k = 0; k < 8; k++) hq[k] = haA[k];
+#pragma unroll
+            for (int k = 0; k < 4; k++) hq[8 + k] = hbA[k];
+        } else {
+            FMRX_TAPS_WAIT(haB, hbB);
+            if constexpr (G + 1 < NG) FMRX_TAPS_ISSUE(haA, hbA, table, (G + 1) * kQC * 4);
+#pragma unroll
+            for (int k = 0; k < 8; k++) hq[k] = haB[k];
+#pragma unroll
+            for (int k = 0; k < 4; k++) hq[8 + k] = hbB[k];
+        }
+#pragma unroll
+        for (int s = 0; s < R + kQC - 1; s++) {
+            const int ii = c * kQC + s;
+            const int jt = p + D * ii;                   // sample index inside the thread's span
+            if (ii < C::NPAIR && jt < C::WT) {
+                const f2 xs = *reinterpret_cast<const f2 *>(tb + au_slot<C::PADP>(jt));   // ds_read_b64, immediate offset
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int q = ii - r;
+                    if (q >= c * kQC && q < (c + 1) * kQC && p + D * q < T)
+                        acc[r] = __builtin_elementwise_fma(xs, (f2){hq[q - c * kQC], hq[q - c * kQC]}, acc[r]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) asm volatile("" : "+v"(acc[r]));
+        au_step<T, D, R, NT, G + 1>(tb, table, acc, haA, hbA, haB, hbB);
+    }
+}
 
 template <int T, int D, int R, int NT>
 __global__ __launch_bounds__(NT) void audio_fir_kernel(const float *__restrict__ xh, long n_in, int delay,
@@ -63,15 +113,15 @@ __global__ __launch_bounds__(NT) void audio_fir_kernel(const float *__restrict__
     const long a0 = static_cast<long>(blockIdx.x) * (2 * C::HALF);   // first output of the low half
     const long gbase = D * a0 - (T - 1) - delay;                      // input index of window sample 0 (low half)
 
-    // ---- stage both half-windows phase-major: 16-byte loads, 4 samples per lane per step.
-    // xh is 16-byte aligned at index 0, so chunks start at multiples of 4 (also for
-    // negative indices = history); `off` = where the window starts inside its first chunk.
+    // ---- stage both half-windows: 16-byte loads, 4 samples per lane per step.  xh is
+    // 16-byte aligned at index 0, so chunks start at multiples of 4 (also for negative
+    // indices = history); `off` = where the window starts inside its first chunk.
     const long gal = gbase & ~3L;
     const int off = static_cast<int>(gbase - gal);
     constexpr int NCH4 = (C::WL + 3) / 4 + 1;
     constexpr int NIT = (2 * NCH4 + NT - 1) / NT;
+    constexpr int DUMP = (C::NSLOT - 1) * 8;             // where out-of-window elements go
     f4 v[NIT];
-    // all of a thread's loads first (NIT independent 16-byte loads in flight), then the scatter
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
         const int cc = t + it * NT;
@@ -87,19 +137,20 @@ __global__ __launch_bounds__(NT) void audio_fir_kernel(const float *__restrict__
             const int half = cc >= NCH4 ? 1 : 0;
             const int c = cc - half * NCH4;
             const long g0 = gal + static_cast<long>(half) * (D * C::HALF) + 4L * c;
-            int j = 4 * c - off;                 // window index of v.x
-            int p = (j + 4 * D) % D;             // j >= -3, keep the operand non-negative
-            int i = (j + 4 * D) / D - 4;
+            const int j0 = 4 * c - off;                  // window index of v.x; >= -3
+            const int jq = ((j0 + C::PADP) * (65536 / C::PADP + 1)) >> 16;   // (j0 + PADP) / PADP, exact for j0 + PADP < 65536
+            int rem = j0 + C::PADP - jq * C::PADP;       // j0 mod PADP (j0 shifted to stay non-negative)
+            int addr = (j0 + jq - 1) * 8 + half * 4;     // slot of j0: (j0 + j0/PADP)*8
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const float val = (g0 + e < n_in) ? v[it][e] : 0.0f;
-                if (j >= 0 && j < C::WL)
-                    *reinterpret_cast<float *>(ldsb + p * C::PH_BYTES + (i / R) * C::CHB + (i % R) * 8 + half * 4) = val;
-                j++;
-                p++;
-                if (p == D) {
-                    p = 0;
-                    i++;
+                const bool ok = static_cast<unsigned>(j0 + e) < static_cast<unsigned>(C::WL);
+                *reinterpret_cast<float *>(ldsb + (ok ? addr : DUMP)) = val;
+                addr += 8;
+                rem++;
+                if (rem == C::PADP) {                    // crossed into the next thread-stride: skip its pad slot
+                    rem = 0;
+                    addr += 8;
                 }
             }
         }
@@ -109,41 +160,12 @@ __global__ __launch_bounds__(NT) void audio_fir_kernel(const float *__restrict__
     f2 acc[R];
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = (f2){0.0f, 0.0f};
-
-#pragma unroll
-    for (int p = 0; p < D; p++) {
-        // the thread's pairs of branch p: i = t*R + ii, ii = 0 .. NPAIR-1
-        f2 xs[2 * C::NRD];
-#pragma unroll
-        for (int k = 0; k < C::NRD; k++) {
-            const int ii = 2 * k;
-            const f4 v = *reinterpret_cast<const f4 *>(ldsb + p * C::PH_BYTES + (t + ii / R) * C::CHB + (ii % R) * 8);
-            xs[ii] = (f2){v.x, v.y};
-            xs[ii + 1] = (f2){v.z, v.w};
-        }
-#pragma unroll
-        for (int c = 0; c < C::NC; c++) {
-            f8 ha;
-            f4 hb;
-            asm volatile("s_load_dwordx8 %0, %2, %3\n\ts_load_dwordx4 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&s"(ha), "=&s"(hb)
-                         : "s"(table), "i"((p * C::NC + c) * kQC * 4), "i"((p * C::NC + c) * kQC * 4 + 32));
-            const float hq[kQC] = {ha[0], ha[1], ha[2], ha[3], ha[4], ha[5], ha[6], ha[7], hb[0], hb[1], hb[2], hb[3]};
-#pragma unroll
-            for (int s = 0; s < R + kQC - 1; s++) {
-                const int ii = c * kQC + s;
-                if (ii < C::NPAIR && p + D * ii < C::WT) {
-#pragma unroll
-                    for (int r = 0; r < R; r++) {
-                        const int q = ii - r;
-                        if (q >= c * kQC && q < (c + 1) * kQC && p + D * q < T)
-                            acc[r] = __builtin_elementwise_fma(xs[ii], (f2){hq[q - c * kQC], hq[q - c * kQC]}, acc[r]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < R; r++) asm volatile("" : "+v"(acc[r]));
-        }
+    {
+        const uint8_t *tb = ldsb + t * ((C::PADP + 1) * 8);   // slot of this thread's first sample
+        f8 haA, haB;
+        f4 hbA, hbB;
+        FMRX_TAPS_ISSUE(haA, hbA, table, 0);
+        au_step<T, D, R, NT, 0>(tb, table, acc, haA, hbA, haB, hbB);
     }
 
     // ---- R consecutive outputs in each half; f32 and/or s16 ----
