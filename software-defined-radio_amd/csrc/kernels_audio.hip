@@ -101,27 +101,14 @@ __device__ __forceinline__ void au_step(const uint8_t *tb, const float *__restri
     }
 }
 
-template <int T, int D, int R, int NT>
-__global__ __launch_bounds__(NT) void audio_fir_kernel(const float *__restrict__ xh, long n_in, int delay,
-                                                        const float *__restrict__ table, float *__restrict__ y,
-                                                        int16_t *__restrict__ pcm, int wrap, long n_out)
+// loads of one tile: NIT independent 16-byte loads per thread, all in flight together
+template <int T, int D, int R, int NT, int NIT>
+__device__ __forceinline__ void au_fetch(const float *__restrict__ xh, long n_in, int delay, long tile, int t, f4 (&v)[NIT])
 {
     using C = AuCfg<T, D, R, NT>;
-    extern __shared__ f4 lds4[];
-    uint8_t *ldsb = reinterpret_cast<uint8_t *>(lds4);
-    const int t = threadIdx.x;
-    const long a0 = static_cast<long>(blockIdx.x) * (2 * C::HALF);   // first output of the low half
-    const long gbase = D * a0 - (T - 1) - delay;                      // input index of window sample 0 (low half)
-
-    // ---- stage both half-windows: 16-byte loads, 4 samples per lane per step.  xh is
-    // 16-byte aligned at index 0, so chunks start at multiples of 4 (also for negative
-    // indices = history); `off` = where the window starts inside its first chunk.
-    const long gal = gbase & ~3L;
-    const int off = static_cast<int>(gbase - gal);
     constexpr int NCH4 = (C::WL + 3) / 4 + 1;
-    constexpr int NIT = (2 * NCH4 + NT - 1) / NT;
-    constexpr int DUMP = (C::NSLOT - 1) * 8;             // where out-of-window elements go
-    f4 v[NIT];
+    const long gbase = D * tile * (2 * C::HALF) - (T - 1) - delay;   // input index of window sample 0 (low half)
+    const long gal = gbase & ~3L;
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
         const int cc = t + it * NT;
@@ -130,54 +117,84 @@ __global__ __launch_bounds__(NT) void audio_fir_kernel(const float *__restrict__
         v[it] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
         if (cc < 2 * NCH4 && g0 < n_in) v[it] = *reinterpret_cast<const f4 *>(xh + g0);
     }
+}
+
+// Persistent workgroups: the next tile's samples are loaded into registers while
+// this tile's FMAs run, so HBM latency is not in front of the barrier.
+template <int T, int D, int R, int NT>
+__global__ __launch_bounds__(NT) void audio_fir_kernel(const float *__restrict__ xh, long n_in, int delay,
+                                                        const float *__restrict__ table, float *__restrict__ y,
+                                                        int16_t *__restrict__ pcm, int wrap, long n_out, long n_tiles)
+{
+    using C = AuCfg<T, D, R, NT>;
+    extern __shared__ f4 lds4[];
+    uint8_t *ldsb = reinterpret_cast<uint8_t *>(lds4);
+    const int t = threadIdx.x;
+    constexpr int NCH4 = (C::WL + 3) / 4 + 1;
+    constexpr int NIT = (2 * NCH4 + NT - 1) / NT;
+    constexpr int DUMP = (C::NSLOT - 1) * 8;             // where out-of-window elements go
+
+    f4 v[NIT];
+    long tile = blockIdx.x;
+    if (tile < n_tiles) au_fetch<T, D, R, NT, NIT>(xh, n_in, delay, tile, t, v);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const long a0 = tile * (2 * C::HALF);            // first output of the low half
+        const long gbase = D * a0 - (T - 1) - delay;
+        const long gal = gbase & ~3L;
+        const int off = static_cast<int>(gbase - gal);   // where the window starts inside its first 16-byte chunk
+        // ---- scatter the prefetched samples into (lo,hi) pair slots, stream order + pads ----
 #pragma unroll
-    for (int it = 0; it < NIT; it++) {
-        const int cc = t + it * NT;
-        if (cc < 2 * NCH4) {
-            const int half = cc >= NCH4 ? 1 : 0;
-            const int c = cc - half * NCH4;
-            const long g0 = gal + static_cast<long>(half) * (D * C::HALF) + 4L * c;
-            const int j0 = 4 * c - off;                  // window index of v.x; >= -3
-            const int jq = ((j0 + C::PADP) * (65536 / C::PADP + 1)) >> 16;   // (j0 + PADP) / PADP, exact for j0 + PADP < 65536
-            int rem = j0 + C::PADP - jq * C::PADP;       // j0 mod PADP (j0 shifted to stay non-negative)
-            int addr = (j0 + jq - 1) * 8 + half * 4;     // slot of j0: (j0 + j0/PADP)*8
+        for (int it = 0; it < NIT; it++) {
+            const int cc = t + it * NT;
+            if (cc < 2 * NCH4) {
+                const int half = cc >= NCH4 ? 1 : 0;
+                const int c = cc - half * NCH4;
+                const long g0 = gal + static_cast<long>(half) * (D * C::HALF) + 4L * c;
+                const int j0 = 4 * c - off;                  // window index of v.x; >= -3
+                const int jq = ((j0 + C::PADP) * (65536 / C::PADP + 1)) >> 16;   // (j0 + PADP) / PADP
+                int rem = j0 + C::PADP - jq * C::PADP;       // j0 mod PADP
+                int addr = (j0 + jq - 1) * 8 + half * 4;     // slot of j0: (j0 + j0/PADP)*8
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const float val = (g0 + e < n_in) ? v[it][e] : 0.0f;
-                const bool ok = static_cast<unsigned>(j0 + e) < static_cast<unsigned>(C::WL);
-                *reinterpret_cast<float *>(ldsb + (ok ? addr : DUMP)) = val;
-                addr += 8;
-                rem++;
-                if (rem == C::PADP) {                    // crossed into the next thread-stride: skip its pad slot
-                    rem = 0;
+                for (int e = 0; e < 4; e++) {
+                    const float val = (g0 + e < n_in) ? v[it][e] : 0.0f;
+                    const bool ok = static_cast<unsigned>(j0 + e) < static_cast<unsigned>(C::WL);
+                    *reinterpret_cast<float *>(ldsb + (ok ? addr : DUMP)) = val;
                     addr += 8;
+                    rem++;
+                    if (rem == C::PADP) {                    // next thread-stride: skip its pad slot
+                        rem = 0;
+                        addr += 8;
+                    }
                 }
             }
         }
-    }
-    __syncthreads();
+        __syncthreads();
+        const long next = tile + gridDim.x;
+        if (next < n_tiles) au_fetch<T, D, R, NT, NIT>(xh, n_in, delay, next, t, v);
 
-    f2 acc[R];
+        f2 acc[R];
 #pragma unroll
-    for (int r = 0; r < R; r++) acc[r] = (f2){0.0f, 0.0f};
-    {
-        const uint8_t *tb = ldsb + t * ((C::PADP + 1) * 8);   // slot of this thread's first sample
-        f8 haA, haB;
-        f4 hbA, hbB;
-        FMRX_TAPS_ISSUE(haA, hbA, table, 0);
-        au_step<T, D, R, NT, 0>(tb, table, acc, haA, hbA, haB, hbB);
-    }
+        for (int r = 0; r < R; r++) acc[r] = (f2){0.0f, 0.0f};
+        {
+            const uint8_t *tb = ldsb + t * ((C::PADP + 1) * 8);   // slot of this thread's first sample
+            f8 haA, haB;
+            f4 hbA, hbB;
+            FMRX_TAPS_ISSUE(haA, hbA, table, 0);
+            au_step<T, D, R, NT, 0>(tb, table, acc, haA, hbA, haB, hbB);
+        }
+        __syncthreads();   // all reads of this tile done before the next scatter
 
-    // ---- R consecutive outputs in each half; f32 and/or s16 ----
+        // ---- R consecutive outputs in each half; f32 and/or s16 ----
 #pragma unroll
-    for (int half = 0; half < 2; half++) {
-        const long k = a0 + static_cast<long>(half) * C::HALF + static_cast<long>(t) * R;
+        for (int half = 0; half < 2; half++) {
+            const long k = a0 + static_cast<long>(half) * C::HALF + static_cast<long>(t) * R;
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            const float v = half ? acc[r].y : acc[r].x;
-            if (k + r < n_out) {
-                if (y) y[k + r] = v;
-                if (pcm) pcm[k + r] = pcm_pack(v, wrap);
+            for (int r = 0; r < R; r++) {
+                const float o = half ? acc[r].y : acc[r].x;
+                if (k + r < n_out) {
+                    if (y) y[k + r] = o;
+                    if (pcm) pcm[k + r] = pcm_pack(o, wrap);
+                }
             }
         }
     }
@@ -190,9 +207,12 @@ int launch_fast(const AudioPlan &pl, const float *d_x, size_t n_in, int delay, f
     constexpr int R = 4, NT = 256;
     using C = AuCfg<T, D, R, NT>;
     const long n_out = static_cast<long>(n_in / D);
-    const unsigned grid = static_cast<unsigned>((n_out + 2 * C::HALF - 1) / (2 * C::HALF));
+    const long n_tiles = (n_out + 2 * C::HALF - 1) / (2 * C::HALF);
+    long per_cu = (160 * 1024) / C::LDS_BYTES;
+    if (per_cu > 4) per_cu = 4;
+    const unsigned grid = static_cast<unsigned>(n_tiles < 256 * per_cu ? n_tiles : 256 * per_cu);
     hipLaunchKernelGGL((audio_fir_kernel<T, D, R, NT>), dim3(grid), dim3(NT), C::LDS_BYTES, stream, d_x,
-                       static_cast<long>(n_in), delay, pl.table.p, d_y, d_pcm, wrap, n_out);
+                       static_cast<long>(n_in), delay, pl.table.p, d_y, d_pcm, wrap, n_out, n_tiles);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FMRX_EHIP, "launch audio_fir_kernel<%d,%d>: %s", T, D, hipGetErrorString(e));
     return FMRX_OK;
