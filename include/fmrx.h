@@ -65,6 +65,12 @@ FMRX_API int fmrx_device_count(void);
 /* select the device used by the host-pointer stage functions of this thread */
 FMRX_API int fmrx_set_device(int device);
 
+/* page-locked host buffers for the block-streaming callers (faster, truly
+ * asynchronous H2D/D2H); free with fmrx_host_free.  Plain malloc memory works
+ * everywhere too. */
+FMRX_API int fmrx_host_alloc(void **out, size_t bytes);
+FMRX_API int fmrx_host_free(void *p);
+
 /* ------------------------------------------------------------------ */
 /* filter-coefficient API (host, float32 bit-compatible)                */
 /* ------------------------------------------------------------------ */

@@ -87,6 +87,8 @@ _sig("fmrx_version", [], C.c_char_p)
 _sig("fmrx_last_error", [], C.c_char_p)
 _sig("fmrx_device_count", [])
 _sig("fmrx_set_device", [_int])
+_sig("fmrx_host_alloc", [C.POINTER(_vp), _sz])
+_sig("fmrx_host_free", [_vp])
 _sig("fmrx_impulse_response_lpf", [_flt, _flt, C.c_ushort, _f32p])
 _sig("fmrx_band_pass", [_flt, _flt, _flt, C.c_ushort, _f32p])
 _sig("fmrx_u8_to_f32", [_u8p, _sz, _f32p])

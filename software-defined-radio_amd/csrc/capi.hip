@@ -100,6 +100,20 @@ int fmrx_set_device(int device)
     return FMRX_OK;
 }
 
+int fmrx_host_alloc(void **out, size_t bytes)
+{
+    if (!out || bytes == 0) return fail(FMRX_EINVAL, "host_alloc: bad arguments");
+    FMRX_TRY(require_device());
+    FMRX_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return FMRX_OK;
+}
+
+int fmrx_host_free(void *p)
+{
+    if (p) FMRX_HIP(hipHostFree(p));
+    return FMRX_OK;
+}
+
 // ---- element-wise stages ---------------------------------------------------------
 int fmrx_u8_to_f32(const uint8_t *raw, size_t n, float *out)
 {

@@ -102,6 +102,19 @@ int audio_plan_init(AudioPlan &pl, const float *h, int taps, int decim);
 int audio_fir_launch(const AudioPlan &pl, const float *d_x, size_t n_in, int delay, float *d_y, int16_t *d_pcm, int wrap,
                      hipStream_t stream, bool force_generic);
 
+// ---- rational resampler (kernels_resample.hip) ------------------------------------
+struct ResamplePlan {
+    int taps = 0, decim = 0, upsamp = 0;
+    int J = 0, JP = 0;         // taps per polyphase row, padded row length
+    int span = 0;              // input samples one 256-output tile stages in LDS
+    bool fast = false;
+    DevBuf<float> table;       // polyphase-major taps [upsamp][JP]
+    DevBuf<float> h;           // plain taps (generic path)
+};
+int resample_plan_init(ResamplePlan &pl, const float *h, int taps, int decim, int upsamp);
+int resample_launch(const ResamplePlan &pl, const float *d_x, size_t n_in, int delay, float *d_y, hipStream_t stream,
+                    bool force_generic);
+
 // ---- generic kernels (kernels_generic.hip) ----------------------------------
 // y[k] = sum_{n<taps} h[n]*x[decim*k - n], sequential mul+add in n (bit-compatible
 // with the reference's evaluation order).  x[-(taps-1)..-1] must be readable.

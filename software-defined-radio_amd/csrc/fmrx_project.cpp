@@ -38,8 +38,11 @@
 namespace {
 constexpr size_t kQueueElems = 6;
 
+// blocks travel as indices into a fixed pool of page-locked buffers (no per-block
+// allocation, DMA-able by the GPU): `full` carries read blocks to the consumer,
+// `free_` returns them
 struct BlockQueue {
-    std::queue<std::vector<uint8_t>> q;
+    std::queue<int> full, free_;
     std::mutex m;
     std::condition_variable cv;
     bool done = false;
@@ -104,59 +107,88 @@ int main(int argc, char *argv[])
         return 2;
     }
 
+    constexpr int kPool = static_cast<int>(kQueueElems) + 2;   // 6 queued + 1 being read + 1 being processed
+    std::vector<uint8_t *> pool(kPool, nullptr);
+    for (int i = 0; i < kPool; i++) {
+        void *ptr = nullptr;
+        if (fmrx_host_alloc(&ptr, block_bytes) != FMRX_OK) {
+            std::fprintf(stderr, "fmrx: %s\n", fmrx_last_error());
+            return 2;
+        }
+        pool[i] = static_cast<uint8_t *>(ptr);
+    }
     BlockQueue bq;
+    for (int i = 0; i < kPool; i++) bq.free_.push(i);
     std::thread producer([&] {
         for (;;) {
-            std::vector<uint8_t> blk(block_bytes);
-            const size_t got = std::fread(blk.data(), 1, block_bytes, stdin);
-            if (got != block_bytes) break;  // EOF: the partial block is ignored, as in the reference
-            std::unique_lock<std::mutex> lk(bq.m);
-            bq.cv.wait(lk, [&] { return bq.q.size() < kQueueElems; });
-            bq.q.push(std::move(blk));
+            int idx;
+            {
+                std::unique_lock<std::mutex> lk(bq.m);
+                bq.cv.wait(lk, [&] { return (!bq.free_.empty() && bq.full.size() < kQueueElems) || bq.done; });
+                if (bq.done) return;
+                idx = bq.free_.front();
+                bq.free_.pop();
+            }
+            const size_t got = std::fread(pool[idx], 1, block_bytes, stdin);
+            std::lock_guard<std::mutex> lk(bq.m);
+            if (got != block_bytes) {  // EOF: the partial block is ignored, as in the reference
+                bq.done = true;
+                bq.cv.notify_all();
+                return;
+            }
+            bq.full.push(idx);
             bq.cv.notify_all();
         }
-        std::lock_guard<std::mutex> lk(bq.m);
-        bq.done = true;
-        bq.cv.notify_all();
     });
 
     const size_t n_out = fmrx_pipeline_n_audio(pl, block_bytes) * channels;
-    std::vector<int16_t> pcm(n_out);
+    int16_t *pcm = nullptr;
+    {
+        void *ptr = nullptr;
+        if (fmrx_host_alloc(&ptr, n_out * sizeof(int16_t)) != FMRX_OK) {
+            std::fprintf(stderr, "fmrx: %s\n", fmrx_last_error());
+            return 2;
+        }
+        pcm = static_cast<int16_t *>(ptr);
+    }
     size_t blocks = 0;
     int rc = 0;
     for (;;) {
-        std::vector<uint8_t> blk;
+        int idx;
         {
             std::unique_lock<std::mutex> lk(bq.m);
-            bq.cv.wait(lk, [&] { return !bq.q.empty() || bq.done; });
-            if (bq.q.empty()) break;
-            blk = std::move(bq.q.front());
-            bq.q.pop();
-            bq.cv.notify_all();
+            bq.cv.wait(lk, [&] { return !bq.full.empty() || bq.done; });
+            if (bq.full.empty()) break;
+            idx = bq.full.front();
+            bq.full.pop();
         }
-        if (fmrx_pipeline_process(pl, blk.data(), blk.size(), nullptr, pcm.data(),
+        if (fmrx_pipeline_process(pl, pool[idx], block_bytes, nullptr, pcm,
                                   saturate ? FMRX_PCM_SATURATE : FMRX_PCM_WRAP) != FMRX_OK) {
             std::fprintf(stderr, "fmrx: %s\n", fmrx_last_error());
             rc = 3;
-            break;
-        }
-        if (std::fwrite(pcm.data(), sizeof(int16_t), pcm.size(), stdout) != pcm.size()) {
+        } else if (std::fwrite(pcm, sizeof(int16_t), n_out, stdout) != n_out) {
             std::fprintf(stderr, "fmrx: short write on stdout\n");
             rc = 4;
-            break;
         }
+        {
+            std::lock_guard<std::mutex> lk(bq.m);
+            bq.free_.push(idx);
+            bq.cv.notify_all();
+        }
+        if (rc) break;
         blocks++;
     }
-    if (rc != 0) {  // unblock and retire the producer
+    if (rc != 0) {  // retire the producer
         std::lock_guard<std::mutex> lk(bq.m);
-        while (!bq.q.empty()) bq.q.pop();
+        bq.done = true;
         bq.cv.notify_all();
-        std::fclose(stdin);
     }
     producer.join();
     std::fflush(stdout);
     std::fprintf(stderr, "End of input stream reached after %zu blocks\n", blocks);
     fmrx_pipeline_destroy(pl);
+    for (auto *b : pool) fmrx_host_free(b);
+    fmrx_host_free(pcm);
     if (rc) return rc;
     return compat_exit ? 1 : 0;
 }

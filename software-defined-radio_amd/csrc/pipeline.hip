@@ -42,7 +42,7 @@ struct fmrx_pipeline {
     hipStream_t stream = nullptr;  // used by the host-buffer entry point
     FePlan fe;
     AudioPlan audio;
-    DevBuf<float> h_audio_rs;  // resampler taps (modes 2, 3)
+    ResamplePlan rs;           // resampler (modes 2, 3)
     DevBuf<float> h_carrier, h_stereo;
 
     DevBuf<uint8_t> in;
@@ -97,9 +97,7 @@ int carry_history(fmrx_pipeline *pl, float *buf, int keep, size_t n_block, hipSt
 
 int audio_stage(fmrx_pipeline *pl, const float *d_x, size_t n_in, int delay, float *d_y, hipStream_t s)
 {
-    if (pl->resample)
-        return k_resample_generic(d_x - delay, n_in, pl->h_audio_rs.p, pl->p.audio_taps, pl->p.audio_decim,
-                                  pl->p.audio_upsamp, d_y, s);
+    if (pl->resample) return resample_launch(pl->rs, d_x, n_in, delay, d_y, s, pl->force_generic);
     return audio_fir_launch(pl->audio, d_x, n_in, delay, d_y, nullptr, 0, s, pl->force_generic);
 }
 
@@ -189,8 +187,7 @@ int fmrx_pipeline_create(fmrx_pipeline **out, const fmrx_params *p, int channels
         const int design_fs = pl->resample ? p->if_Fs * p->audio_upsamp : p->if_Fs;
         design_lpf(static_cast<float>(design_fs), static_cast<float>(16000), p->audio_taps, h.data());
         if (pl->resample) {
-            FMRX_TRY(pl->h_audio_rs.alloc(p->audio_taps));
-            FMRX_HIP(hipMemcpy(pl->h_audio_rs.p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+            FMRX_TRY(resample_plan_init(pl->rs, h.data(), p->audio_taps, p->audio_decim, p->audio_upsamp));
         } else {
             FMRX_TRY(audio_plan_init(pl->audio, h.data(), p->audio_taps, p->audio_decim));
         }
