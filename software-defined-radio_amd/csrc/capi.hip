@@ -323,7 +323,7 @@ int fmrx_fm_pll(const float *in, size_t n, float *nco_out, float *state, float f
     FMRX_TRY(s.c.ensure(6));
     FMRX_TRY(h2d(s.a.p, in, n * sizeof(float)));
     FMRX_TRY(h2d(s.c.p, state, 6 * sizeof(float)));
-    FMRX_TRY(k_fm_pll(s.a.p, n, s.b.p, s.c.p, freq, Fs, ncoScale, phaseAdjust, normBandwidth, nullptr));
+    FMRX_TRY(k_fm_pll(s.a.p, n, s.b.p, s.c.p, freq, Fs, ncoScale, phaseAdjust, normBandwidth, 0, nullptr));
     FMRX_TRY(d2h(nco_out, s.b.p, (n + 1) * sizeof(float)));
     return d2h(state, s.c.p, 6 * sizeof(float));
 }

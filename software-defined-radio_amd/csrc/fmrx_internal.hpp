@@ -137,8 +137,9 @@ int k_split_if(const float *d_if, size_t n, float *d_i, float *d_q, hipStream_t 
 int k_pcm16(const float *d_a, size_t n, int16_t *d_out, int wrap, hipStream_t s);
 int k_pcm16_stereo(const float *d_l, const float *d_r, size_t n, int16_t *d_out, int wrap, hipStream_t s);
 int k_all_pass(const float *d_in, size_t n, const float *d_state, size_t nstate, float *d_out, hipStream_t s);
+// fast != 0: shared double-precision argument reduction + hardware sin/cos (see pll_kernel)
 int k_fm_pll(const float *d_in, size_t n, float *d_out, float *d_state, float freq, float Fs, float ncoScale,
-             float phaseAdjust, float normBandwidth, hipStream_t s);
+             float phaseAdjust, float normBandwidth, int fast, hipStream_t s);
 int k_mix(const float *d_bpf, const float *d_pll, size_t n, float *d_mix, hipStream_t s);
 int k_combine(const float *d_st, const float *d_mono, size_t n, float *d_l, float *d_r, hipStream_t s);
 int k_upsample(const float *d_x, size_t n, float *d_xu, int up, hipStream_t s);

@@ -219,6 +219,15 @@ __global__ void fill_u8_kernel(uint8_t *d, size_t n, uint8_t v)
 // ---- PLL / NCO (src/filter.cpp:32-80) ---------------------------------------------------
 // A serial float32 recurrence per channel: one lane walks the block.  state[6] =
 // {integrator, phaseEst, feedbackI, feedbackQ, lastOut, trigOffset}; out has n+1.
+//
+// FAST = false: the reference's operations one for one, with the device math
+// library's sinf / cosf / atan2f (argument reduction of trigArg ~ 1e4..1e5 rad is
+// the expensive part: ~0.9 us per sample).
+// FAST = true: the three trigonometric values share one argument reduction done
+// in double (rev = trigArg / 2pi, exact fractional part), then the hardware
+// v_sin_f32 / v_cos_f32 (inputs in revolutions, |error| ~ 1e-6).  Same recurrence,
+// same float32 state updates; only the transcendental evaluation differs.
+template <bool FAST>
 __global__ void pll_kernel(const float *__restrict__ in, size_t n, float *__restrict__ out, float *__restrict__ state,
                            float freq, float Fs, float ncoScale, float phaseAdjust, float normBandwidth)
 {
@@ -230,6 +239,7 @@ __global__ void pll_kernel(const float *__restrict__ in, size_t n, float *__rest
     float trigOffset = state[5];
     out[0] = state[4];
     const double w = 2 * 3.14159265358979323846 * static_cast<double>(freq / Fs);
+    const double inv2pi = 0.15915494309189533577;
     float last = state[4];
     for (size_t k = 0; k < n; k++) {
         const float v = in[k];
@@ -241,10 +251,21 @@ __global__ void pll_kernel(const float *__restrict__ in, size_t n, float *__rest
         phaseEst = (phaseEst + pe) + integrator;
         trigOffset += 1;
         const float trigArg = static_cast<float>(w * static_cast<double>(trigOffset) + static_cast<double>(phaseEst));
-        fbI = cosf(trigArg);
-        fbQ = sinf(trigArg);
-        const float sc = trigArg * ncoScale;
-        last = cosf(sc + phaseAdjust);
+        if (FAST) {
+            const double rev = static_cast<double>(trigArg) * inv2pi;
+            const float fr = static_cast<float>(rev - rint(rev));                 // [-0.5, 0.5] revolutions
+            fbI = __builtin_amdgcn_cosf(fr);
+            fbQ = __builtin_amdgcn_sinf(fr);
+            // cosf(trigArg*ncoScale + phaseAdjust): the float product/sum as in the reference, reduced the same way
+            const float sc = trigArg * ncoScale;
+            const double rev2 = static_cast<double>(sc + phaseAdjust) * inv2pi;
+            last = __builtin_amdgcn_cosf(static_cast<float>(rev2 - rint(rev2)));
+        } else {
+            fbI = cosf(trigArg);
+            fbQ = sinf(trigArg);
+            const float sc = trigArg * ncoScale;
+            last = cosf(sc + phaseAdjust);
+        }
         out[k + 1] = last;
     }
     state[0] = integrator;
@@ -347,10 +368,14 @@ int k_upsample(const float *d_x, size_t n, float *d_xu, int up, hipStream_t s)
 }
 
 int k_fm_pll(const float *d_in, size_t n, float *d_out, float *d_state, float freq, float Fs, float ncoScale,
-             float phaseAdjust, float normBandwidth, hipStream_t s)
+             float phaseAdjust, float normBandwidth, int fast, hipStream_t s)
 {
-    hipLaunchKernelGGL(pll_kernel, dim3(1), dim3(64), 0, s, d_in, n, d_out, d_state, freq, Fs, ncoScale, phaseAdjust,
-                       normBandwidth);
+    if (fast)
+        hipLaunchKernelGGL(pll_kernel<true>, dim3(1), dim3(64), 0, s, d_in, n, d_out, d_state, freq, Fs, ncoScale,
+                           phaseAdjust, normBandwidth);
+    else
+        hipLaunchKernelGGL(pll_kernel<false>, dim3(1), dim3(64), 0, s, d_in, n, d_out, d_state, freq, Fs, ncoScale,
+                           phaseAdjust, normBandwidth);
     FMRX_LAUNCH_CHECK("pll");
     return FMRX_OK;
 }

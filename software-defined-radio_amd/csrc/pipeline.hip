@@ -350,7 +350,7 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
         FMRX_TRY(k_fir_generic(demod, n_if, pl->h_stereo.p, pl->St, 1, pl->bpf.p, s));
         FMRX_TRY(k_fir_generic(demod, n_if, pl->h_carrier.p, pl->St, 1, pl->carrier.p, s));
         FMRX_TRY(k_fm_pll(pl->carrier.p, n_if, pl->pll.p, pl->pll_state.p, 19e3f, static_cast<float>(p.if_Fs), 2.0f,
-                          0.0f, 0.01f, s));
+                          0.0f, 0.01f, pl->force_generic ? 0 : 1, s));
         FMRX_TRY(k_mix(pl->bpf.p, pl->pll.p, n_if, mixer, s));
         FMRX_TRY(audio_stage(pl, mixer, n_if, 0, pl->st_final.p, s));
         FMRX_TRY(k_combine(pl->st_final.p, pl->mono.p, n_au, pl->left.p, pl->right.p, s));
