@@ -443,12 +443,12 @@ __global__ __launch_bounds__(256, (FeWaveCfg<T, D, R>::MINW)) void fe_demod_kern
     }
 }
 
-template <int T, int D>
+template <int T, int D, int R>
 int launch_fused(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist, const float *d_prev_override,
                  float *d_demod, float *d_if, float *d_prev_out, hipStream_t stream)
 {
-    constexpr int R = 8;
     using W = FeWaveCfg<T, D, R>;
+    if (d_hist) d_hist += pl.hist_bytes - W::HBX;   // the kernel reads the last HBX bytes of the history
     const long n_out = static_cast<long>(n_samples / D);
     const long n_wtiles = (n_out + W::STRIDE - 1) / W::STRIDE;
     const long lds_wg = 4L * W::WREGION;
@@ -518,13 +518,16 @@ void build_table(const float *h, std::vector<float> &tab)
 }  // namespace
 
 // bytes of history kept in front of a block: the taps-1 samples the FIR needs,
-// rounded up to 16 bytes, plus decim*8 samples so that the fused kernel's lane 0
-// can recompute the previous block's last IF samples (a multiple of 16 bytes)
-int fe_hist_bytes(int taps, int decim)
+// rounded up to 16 bytes (fe_hist_base), plus decim*kMaxR samples so that the fused
+// kernel's lane 0 can recompute the previous block's last IF samples.  Every
+// kernel reads the LAST bytes of this buffer that it needs.
+constexpr int kMaxR = 12;
+static int fe_hist_base(int taps)
 {
     const int lead = (8 - (taps - 1) % 8) % 8;
-    return 2 * (taps - 1 + lead) + 2 * decim * 8;
+    return 2 * (taps - 1 + lead);
 }
+int fe_hist_bytes(int taps, int decim) { return fe_hist_base(taps) + 2 * decim * kMaxR; }
 
 int fe_plan_init(FePlan &pl, const float *h, int taps, int decim)
 {
@@ -557,7 +560,7 @@ int fe_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uin
                          (!d_hist || reinterpret_cast<uintptr_t>(d_hist) % 16 == 0);
     if (pl.fast && aligned && !force_generic) {
         // the IF-only kernels read just the last 2*(taps-1+lead) bytes of the history
-        const uint8_t *h1 = d_hist ? d_hist + 2 * pl.decim * 8 : nullptr;
+        const uint8_t *h1 = d_hist ? d_hist + (pl.hist_bytes - fe_hist_base(pl.taps)) : nullptr;
 #define X(T_, D_) \
     if (pl.taps == T_ && pl.decim == D_) return launch_fast<T_, D_>(pl, d_iq, n_samples, h1, d_if, stream);
         FMRX_FE_CASES(X)
@@ -575,9 +578,14 @@ int fe_demod_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, con
                     const float *d_prev_override, float *d_demod, float *d_if, float *d_prev_out, hipStream_t stream)
 {
     if (n_samples / pl.decim == 0) return FMRX_OK;
+    // experiment switch: 12 outputs per lane for the headline shape (fewer conversions per output,
+    // but 2 waves per SIMD instead of 3); everything else uses 8
+    const char *er = std::getenv("FMRX_FE_R");
+    if (er && std::atoi(er) == 12 && pl.taps == 101 && pl.decim == 10)
+        return launch_fused<101, 10, 12>(pl, d_iq, n_samples, d_hist, d_prev_override, d_demod, d_if, d_prev_out, stream);
 #define X(T_, D_) \
     if (pl.taps == T_ && pl.decim == D_) \
-        return launch_fused<T_, D_>(pl, d_iq, n_samples, d_hist, d_prev_override, d_demod, d_if, d_prev_out, stream);
+        return launch_fused<T_, D_, 8>(pl, d_iq, n_samples, d_hist, d_prev_override, d_demod, d_if, d_prev_out, stream);
     FMRX_FE_CASES(X)
 #undef X
     return fail(FMRX_EINVAL, "fe_demod_launch: no specialised kernel for taps=%d decim=%d", pl.taps, pl.decim);
