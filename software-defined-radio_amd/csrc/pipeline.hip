@@ -76,6 +76,22 @@ __global__ void hist_update_kernel(const uint8_t *__restrict__ old_hist, const u
     new_hist[i] = src >= 0 ? x[src] : old_hist[hb + src];
 }
 
+// One launch for the per-block state carry of the mono path: the front end's byte
+// history (as hist_update_kernel) and the audio stage's float history (the last
+// `keep` demod samples move in front of the buffer; requires n_block >= keep so
+// source and destination do not overlap).
+__global__ void state_carry_kernel(const uint8_t *__restrict__ old_hist, const uint8_t *__restrict__ x, long n_bytes,
+                                   int hb, uint8_t *__restrict__ new_hist, float *__restrict__ buf, int keep,
+                                   long n_block)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < hb) {
+        const long src = static_cast<long>(i) + n_bytes - hb;
+        new_hist[i] = src >= 0 ? x[src] : old_hist[hb + src];
+    }
+    if (i < keep) buf[i] = buf[n_block + i];
+}
+
 int n_if_of(const fmrx_pipeline *pl, size_t n_bytes) { return static_cast<int>((n_bytes / 2) / pl->p.rf_decim); }
 
 size_t n_audio_of(const fmrx_pipeline *pl, size_t n_bytes)
@@ -314,12 +330,9 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
     pl->prev_cur ^= 1;
     pl->prev_override = false;
     if (pl->profiling) FMRX_HIP(hipEventRecord(ev[1], s));
-    {   // I_state/Q_state <- last samples of the block (filter.cpp:182-187), kept as raw bytes
-        const int hb = pl->fe.hist_bytes;
-        hipLaunchKernelGGL(hist_update_kernel, dim3((hb + 255) / 256), dim3(256), 0, s, hist, d_iq,
-                           static_cast<long>(n_bytes), hb, pl->fe_hist[pl->fe_cur ^ 1].p);
-        pl->fe_cur ^= 1;
-    }
+    const int hb = pl->fe.hist_bytes;
+    uint8_t *hist_next = pl->fe_hist[pl->fe_cur ^ 1].p;
+    pl->fe_cur ^= 1;
 
     if (pl->channels == 1 && !pl->resample) {
         // ---- RF_MONO, modes 0/1: audio FIR + decimate + PCM in one kernel (project.cpp:346;
@@ -328,13 +341,27 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
         FMRX_TRY(audio_fir_launch(pl->audio, demod, n_if, 0, dst, d_pcm16, pcm_policy, s, pl->force_generic));
         pl->last_mono = dst;
         if (pl->profiling) FMRX_HIP(hipEventRecord(ev[2], s));
-        FMRX_TRY(carry_history(pl, pl->demod.p, pl->Hd, n_if, s));
+        // carried state for the next block: I_state/Q_state as raw bytes (filter.cpp:182-187) and
+        // state_mono as the demod tail, one launch
+        if (n_if >= static_cast<size_t>(pl->Hd)) {
+            const int nthr = hb > pl->Hd ? hb : pl->Hd;
+            hipLaunchKernelGGL(state_carry_kernel, dim3((nthr + 255) / 256), dim3(256), 0, s, hist, d_iq,
+                               static_cast<long>(n_bytes), hb, hist_next, pl->demod.p, pl->Hd, static_cast<long>(n_if));
+        } else {
+            hipLaunchKernelGGL(hist_update_kernel, dim3((hb + 255) / 256), dim3(256), 0, s, hist, d_iq,
+                               static_cast<long>(n_bytes), hb, hist_next);
+            FMRX_TRY(carry_history(pl, pl->demod.p, pl->Hd, n_if, s));
+        }
         if (pl->profiling) {
             FMRX_HIP(hipEventRecord(ev[3], s));
             pl->calls++;
         }
         return FMRX_OK;
     }
+
+    // I_state/Q_state <- last samples of the block (filter.cpp:182-187), kept as raw bytes
+    hipLaunchKernelGGL(hist_update_kernel, dim3((hb + 255) / 256), dim3(256), 0, s, hist, d_iq,
+                       static_cast<long>(n_bytes), hb, hist_next);
 
     float *out_l = pl->mono.p, *out_r = nullptr;
     pl->last_mono = pl->mono.p;
