@@ -521,7 +521,7 @@ void build_table(const float *h, std::vector<float> &tab)
 // rounded up to 16 bytes (fe_hist_base), plus decim*kMaxR samples so that the fused
 // kernel's lane 0 can recompute the previous block's last IF samples.  Every
 // kernel reads the LAST bytes of this buffer that it needs.
-constexpr int kMaxR = 12;
+constexpr int kMaxR = 8;   // outputs per lane of the fused kernel (12 was measured: no faster, 2 waves/SIMD)
 static int fe_hist_base(int taps)
 {
     const int lead = (8 - (taps - 1) % 8) % 8;
@@ -578,11 +578,6 @@ int fe_demod_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, con
                     const float *d_prev_override, float *d_demod, float *d_if, float *d_prev_out, hipStream_t stream)
 {
     if (n_samples / pl.decim == 0) return FMRX_OK;
-    // experiment switch: 12 outputs per lane for the headline shape (fewer conversions per output,
-    // but 2 waves per SIMD instead of 3); everything else uses 8
-    const char *er = std::getenv("FMRX_FE_R");
-    if (er && std::atoi(er) == 12 && pl.taps == 101 && pl.decim == 10)
-        return launch_fused<101, 10, 12>(pl, d_iq, n_samples, d_hist, d_prev_override, d_demod, d_if, d_prev_out, stream);
 #define X(T_, D_) \
     if (pl.taps == T_ && pl.decim == D_) \
         return launch_fused<T_, D_, 8>(pl, d_iq, n_samples, d_hist, d_prev_override, d_demod, d_if, d_prev_out, stream);
