@@ -377,9 +377,13 @@ __global__ __launch_bounds__(256, (FeWaveCfg<T, D, R>::MINW)) void fe_demod_kern
     const uint32_t flip = 0x80808080u;                         // u ^ 0x80 = (u - 128) as int8
 
     if (w < n_wtiles) fe_dma_tile<T, D, R>(x, hist, n_bytes, w, wl, lane);
+    bool two_stores = false;   // wave-uniform: the previous iteration issued exactly its two demod stores after the DMA
     for (; w < n_wtiles; w += n_waves) {
-        // the tile's bytes (and this wave's older stores) have landed
-        __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
+        // The tile's bytes have landed.  vmcnt counts in issue order, so when the only younger
+        // operations are the previous tile's two demod stores the wait need not cover them
+        // (their ~1 us write acknowledgement would otherwise sit in front of every tile).
+        if (two_stores) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const u4 *lw = reinterpret_cast<const u4 *>(reinterpret_cast<const uint8_t *>(wl) + lane * C::TSTRIDE);
@@ -419,6 +423,9 @@ __global__ __launch_bounds__(256, (FeWaveCfg<T, D, R>::MINW)) void fe_demod_kern
             pi = acc[r].x;
             pq = acc[r].y;
         }
+        // interior tile without the optional IF stream: every lane >= 1 stores, 2 x dwordx4 (>= 2 store
+        // instructions in any case, which is the safe direction for the counted wait above)
+        two_stores = (y_if == nullptr) && (static_cast<long>(w) * W::STRIDE + 63L * R <= n_out);
         if (lane > 0 && kt < n_out) {
             if (kt + R <= n_out) {
                 f4 *dd = reinterpret_cast<f4 *>(demod + kt);
