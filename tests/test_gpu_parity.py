@@ -400,6 +400,27 @@ def test_state_round_trip(fmrx, oracle):
     bits_equal(st[202:302], ref["demod"][-100:])
 
 
+@pytest.mark.parametrize("channels", [1, 2])
+def test_ragged_block_sizes(fmrx, oracle, channels):
+    """Block sizes the reference never uses: tiny blocks, sizes that are not 16-byte multiples
+    (the front end then runs its generic kernel), alternating with large ones so specialised
+    and generic kernels hand the carried state back and forth."""
+    sizes = [3000, 102400, 5000, 2 * 51200 * 3, 3000, 1000 * 2 * 50, 102400 + 2 * 50 * 8]   # bytes; all n % 50 == 0
+    total = sum(sizes)
+    iq = oracle.synth_fm_u8(total // 2, seed=31)
+    pl = fmrx.Pipeline(0, channels, max_block_bytes=max(sizes))
+    po = oracle.pipeline(0, channels)
+    off = 0
+    for nb in sizes:
+        blk = iq[off:off + nb]
+        off += nb
+        out, ref = pl.process(blk), po.process(blk)
+        for k in (("audio",) if channels == 1 else ("audio_l", "audio_r")):
+            err = rms(out[k].astype(np.float64) - ref[k])
+            assert err <= (2e-6 if channels == 1 else AUDIO_ABS_RMS), (nb, k, err)
+        assert len(out["pcm16"]) == channels * len(ref["audio_l"])
+
+
 def test_pipeline_rejects_bad_blocks(fmrx):
     pl = fmrx.Pipeline(0, 1)
     for n in (0, 102401, 102400 + 20, 2 * 102400):   # odd, not a multiple of decims, too large
