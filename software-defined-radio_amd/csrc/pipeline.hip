@@ -301,6 +301,7 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
 {
     if (!pl || !d_iq) return fail(FMRX_EINVAL, "process_dev: null argument");
     FMRX_TRY(check_block(pl, n_bytes));
+    FMRX_HIP(hipSetDevice(pl->device));   // the handle's buffers live there, whatever the caller's current device
     hipStream_t s = static_cast<hipStream_t>(stream);
     const fmrx_params &p = pl->p;
     const size_t n = n_bytes / 2;

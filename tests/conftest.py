@@ -37,6 +37,10 @@ def ref():
 
 @pytest.fixture(scope="session")
 def fmrx():
-    """The product library through its Python host mirror (ctypes over the C-ABI)."""
+    """The product library through its Python host mirror (ctypes over the C-ABI).
+    Builds it first (hipcc, gfx950) when the in-tree .so is missing, e.g. on a fresh checkout."""
     import importlib
+    if not os.path.exists(os.path.join(ROOT, "software-defined-radio_amd", "lib", "libfmrx.so")):
+        import __graft_entry__
+        __graft_entry__.build()
     return importlib.import_module("software-defined-radio_amd")
