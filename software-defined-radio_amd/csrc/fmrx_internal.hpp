@@ -137,9 +137,17 @@ int k_split_if(const float *d_if, size_t n, float *d_i, float *d_q, hipStream_t 
 int k_pcm16(const float *d_a, size_t n, int16_t *d_out, int wrap, hipStream_t s);
 int k_pcm16_stereo(const float *d_l, const float *d_r, size_t n, int16_t *d_out, int wrap, hipStream_t s);
 int k_all_pass(const float *d_in, size_t n, const float *d_state, size_t nstate, float *d_out, hipStream_t s);
-// fast != 0: shared double-precision argument reduction + hardware sin/cos (see pll_kernel)
+// ---- pilot PLL (kernels_pll.hip) ----
+// serial form; fast != 0: shared double-precision argument reduction + hardware sin/cos
 int k_fm_pll(const float *d_in, size_t n, float *d_out, float *d_state, float freq, float Fs, float ncoScale,
              float phaseAdjust, float normBandwidth, int fast, hipStream_t s);
+// parallel-in-time form (fast math): segments with warm-up, bit-for-bit verification against the
+// serial trajectory and serial repair where the loop was not locked.  d_scratch: pll_parallel_scratch_floats(n)
+// floats; d_scratch[2] (as u32) counts blocks that needed a repair (diagnostic).
+constexpr int kPllSegment = 1024, kPllWarmup = 3072;
+size_t pll_parallel_scratch_floats(size_t n);
+int k_fm_pll_parallel(const float *d_in, size_t n, float *d_out, float *d_state, float freq, float Fs, float ncoScale,
+                      float phaseAdjust, float normBandwidth, float *d_scratch, hipStream_t s);
 int k_mix(const float *d_bpf, const float *d_pll, size_t n, float *d_mix, hipStream_t s);
 int k_combine(const float *d_st, const float *d_mono, size_t n, float *d_l, float *d_r, hipStream_t s);
 int k_upsample(const float *d_x, size_t n, float *d_xu, int up, hipStream_t s);

@@ -216,66 +216,6 @@ __global__ void fill_u8_kernel(uint8_t *d, size_t n, uint8_t v)
     if (k < n) d[k] = v;
 }
 
-// ---- PLL / NCO (src/filter.cpp:32-80) ---------------------------------------------------
-// A serial float32 recurrence per channel: one lane walks the block.  state[6] =
-// {integrator, phaseEst, feedbackI, feedbackQ, lastOut, trigOffset}; out has n+1.
-//
-// FAST = false: the reference's operations one for one, with the device math
-// library's sinf / cosf / atan2f (argument reduction of trigArg ~ 1e4..1e5 rad is
-// the expensive part: ~0.9 us per sample).
-// FAST = true: the three trigonometric values share one argument reduction done
-// in double (rev = trigArg / 2pi, exact fractional part), then the hardware
-// v_sin_f32 / v_cos_f32 (inputs in revolutions, |error| ~ 1e-6).  Same recurrence,
-// same float32 state updates; only the transcendental evaluation differs.
-template <bool FAST>
-__global__ void pll_kernel(const float *__restrict__ in, size_t n, float *__restrict__ out, float *__restrict__ state,
-                           float freq, float Fs, float ncoScale, float phaseAdjust, float normBandwidth)
-{
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    const float Cp = 2.666f, Ci = 3.555f;
-    const float Kp = normBandwidth * Cp;
-    const float Ki = (normBandwidth * normBandwidth) * Ci;
-    float integrator = state[0], phaseEst = state[1], fbI = state[2], fbQ = state[3];
-    float trigOffset = state[5];
-    out[0] = state[4];
-    const double w = 2 * 3.14159265358979323846 * static_cast<double>(freq / Fs);
-    const double inv2pi = 0.15915494309189533577;
-    float last = state[4];
-    for (size_t k = 0; k < n; k++) {
-        const float v = in[k];
-        const float eI = v * fbI;
-        const float eQ = v * (-1 * fbQ);
-        const float eD = atan2f(eQ, eI);
-        integrator = integrator + Ki * eD;
-        const float pe = Kp * eD;
-        phaseEst = (phaseEst + pe) + integrator;
-        trigOffset += 1;
-        const float trigArg = static_cast<float>(w * static_cast<double>(trigOffset) + static_cast<double>(phaseEst));
-        if (FAST) {
-            const double rev = static_cast<double>(trigArg) * inv2pi;
-            const float fr = static_cast<float>(rev - rint(rev));                 // [-0.5, 0.5] revolutions
-            fbI = __builtin_amdgcn_cosf(fr);
-            fbQ = __builtin_amdgcn_sinf(fr);
-            // cosf(trigArg*ncoScale + phaseAdjust): the float product/sum as in the reference, reduced the same way
-            const float sc = trigArg * ncoScale;
-            const double rev2 = static_cast<double>(sc + phaseAdjust) * inv2pi;
-            last = __builtin_amdgcn_cosf(static_cast<float>(rev2 - rint(rev2)));
-        } else {
-            fbI = cosf(trigArg);
-            fbQ = sinf(trigArg);
-            const float sc = trigArg * ncoScale;
-            last = cosf(sc + phaseAdjust);
-        }
-        out[k + 1] = last;
-    }
-    state[0] = integrator;
-    state[1] = phaseEst;
-    state[2] = fbI;
-    state[3] = fbQ;
-    state[4] = last;
-    state[5] = trigOffset;
-}
-
 }  // namespace
 
 int k_fir_generic(const float *d_x, size_t n_out, const float *d_h, int taps, int decim, float *d_y, hipStream_t s)
@@ -364,19 +304,6 @@ int k_upsample(const float *d_x, size_t n, float *d_xu, int up, hipStream_t s)
     if (n_out == 0) return FMRX_OK;
     hipLaunchKernelGGL(upsample_kernel, dim3(grid_for(n_out)), dim3(kBlock), 0, s, d_x, n_out, d_xu, up);
     FMRX_LAUNCH_CHECK("upsample");
-    return FMRX_OK;
-}
-
-int k_fm_pll(const float *d_in, size_t n, float *d_out, float *d_state, float freq, float Fs, float ncoScale,
-             float phaseAdjust, float normBandwidth, int fast, hipStream_t s)
-{
-    if (fast)
-        hipLaunchKernelGGL(pll_kernel<true>, dim3(1), dim3(64), 0, s, d_in, n, d_out, d_state, freq, Fs, ncoScale,
-                           phaseAdjust, normBandwidth);
-    else
-        hipLaunchKernelGGL(pll_kernel<false>, dim3(1), dim3(64), 0, s, d_in, n, d_out, d_state, freq, Fs, ncoScale,
-                           phaseAdjust, normBandwidth);
-    FMRX_LAUNCH_CHECK("pll");
     return FMRX_OK;
 }
 

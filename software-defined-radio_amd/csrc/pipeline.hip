@@ -38,6 +38,7 @@ struct fmrx_pipeline {
     bool keep_if = false;        // materialise the IF I/Q stream (diagnostics / read_tap)
     bool prev_override = false;  // the next block takes IF[-1] from prev_iq (after set_state)
     bool if_valid = false;       // ifb holds the last block's IF samples
+    bool pll_warm = false;       // the PLL has seen a block since reset / set_state (its state is a locked one)
 
     hipStream_t stream = nullptr;  // used by the host-buffer entry point
     FePlan fe;
@@ -51,7 +52,7 @@ struct fmrx_pipeline {
     DevBuf<float> prev_iq[2];
     int prev_cur = 0;
     DevBuf<float> ifb, demod, mono, tmp_hist;
-    DevBuf<float> carrier, bpf, pll, pll_state, mixer, st_final, left, right;
+    DevBuf<float> carrier, bpf, pll, pll_state, pll_scratch, mixer, st_final, left, right;
     DevBuf<float> out_f32;
     DevBuf<int16_t> out_pcm;
 
@@ -135,6 +136,7 @@ int reset_state(fmrx_pipeline *pl)
     pl->fe_cur = pl->prev_cur = 0;
     pl->prev_override = false;
     pl->if_valid = false;
+    pl->pll_warm = false;
     return FMRX_OK;
 }
 
@@ -231,6 +233,8 @@ int fmrx_pipeline_create(fmrx_pipeline **out, const fmrx_params *p, int channels
             FMRX_TRY(pl->bpf.alloc(n_if + 16));
             FMRX_TRY(pl->pll.alloc(n_if + 17));
             FMRX_TRY(pl->pll_state.alloc(8));
+            FMRX_TRY(pl->pll_scratch.alloc(pll_parallel_scratch_floats(n_if)));
+            FMRX_HIP(hipMemset(pl->pll_scratch.p, 0, 8 * sizeof(float)));
             FMRX_TRY(pl->mixer.alloc(pl->Hm + n_if + 16));
             FMRX_TRY(pl->st_final.alloc(n_au));
             FMRX_TRY(pl->left.alloc(n_au));
@@ -377,8 +381,23 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
         if (pl->profiling) FMRX_HIP(hipEventRecord(ev[2], s));
         FMRX_TRY(k_fir_generic(demod, n_if, pl->h_stereo.p, pl->St, 1, pl->bpf.p, s));
         FMRX_TRY(k_fir_generic(demod, n_if, pl->h_carrier.p, pl->St, 1, pl->carrier.p, s));
-        FMRX_TRY(k_fm_pll(pl->carrier.p, n_if, pl->pll.p, pl->pll_state.p, 19e3f, static_cast<float>(p.if_Fs), 2.0f,
-                          0.0f, 0.01f, pl->force_generic ? 0 : 1, s));
+        if (pl->force_generic)
+            FMRX_TRY(k_fm_pll(pl->carrier.p, n_if, pl->pll.p, pl->pll_state.p, 19e3f, static_cast<float>(p.if_Fs), 2.0f,
+                              0.0f, 0.01f, 0, s));
+        else {
+            // a stream's first block starts unlocked: walk its first samples serially so that the
+            // segment lanes extrapolate from a locked state; later blocks start locked already
+            size_t head = 0;
+            if (!pl->pll_warm) {
+                head = n_if < 4096 ? n_if : 4096;
+                FMRX_TRY(k_fm_pll(pl->carrier.p, head, pl->pll.p, pl->pll_state.p, 19e3f, static_cast<float>(p.if_Fs),
+                                  2.0f, 0.0f, 0.01f, 1, s));
+            }
+            if (n_if > head)
+                FMRX_TRY(k_fm_pll_parallel(pl->carrier.p + head, n_if - head, pl->pll.p + head, pl->pll_state.p, 19e3f,
+                                           static_cast<float>(p.if_Fs), 2.0f, 0.0f, 0.01f, pl->pll_scratch.p, s));
+            pl->pll_warm = true;
+        }
         FMRX_TRY(k_mix(pl->bpf.p, pl->pll.p, n_if, mixer, s));
         FMRX_TRY(audio_stage(pl, mixer, n_if, 0, pl->st_final.p, s));
         FMRX_TRY(k_combine(pl->st_final.p, pl->mono.p, n_au, pl->left.p, pl->right.p, s));
@@ -547,6 +566,7 @@ int fmrx_pipeline_set_state(fmrx_pipeline *pl, const float *state, size_t n)
     }
     FMRX_HIP(hipMemcpy(pl->demod.p, dh.data(), pl->Hd * sizeof(float), hipMemcpyHostToDevice));
     pl->prev_override = true;   // the fused front end would otherwise recompute IF[-1] from the byte history
+    pl->pll_warm = false;
     return FMRX_OK;
 }
 

