@@ -28,9 +28,10 @@
 //    the warm-up it has (normally exactly) merged with the serial trajectory.
 //    Nothing is assumed: a second kernel compares, for every segment, the state a
 //    lane had at its segment start with the state its predecessor ended on, and a
-//    third re-runs serially from the first segment that does not match bit for
-//    bit (loop not locked: stream start, drop-outs).  The result is therefore the
-//    serial kernel's result by construction; only the time differs.
+//    third walks the recurrence serially from every segment that does not match
+//    bit for bit (loop not locked: stream start, drop-outs, phase jumps) until it
+//    has re-merged with a lane.  The result is therefore the serial kernel's
+//    result by construction; only the time differs.
 //
 // FAST = false (stage API, generic path) uses sinf/cosf/atan2f of the device math
 // library, operation for operation as the reference.
@@ -138,36 +139,63 @@ __global__ void pll_segments_kernel(const float *__restrict__ in, long n, float 
     store_state(seg + sg * 16, s);
 }
 
-// first segment whose start state is not, bit for bit, its predecessor's end state
-__global__ void pll_check_kernel(const float *__restrict__ seg, long nseg, unsigned long long *first_bad)
+// mark every segment whose start state is not, bit for bit, its predecessor's end state
+__global__ void pll_check_kernel(const float *__restrict__ seg, long nseg, unsigned long long *__restrict__ badmask)
 {
     const long sg = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (sg < 1 || sg >= nseg) return;
     const unsigned *cur = reinterpret_cast<const unsigned *>(seg + sg * 16 + 8);
     const unsigned *prv = reinterpret_cast<const unsigned *>(seg + (sg - 1) * 16);
-    if (cur[0] != prv[0] || cur[1] != prv[1]) atomicMin(first_bad, static_cast<unsigned long long>(sg));
+    if (cur[0] != prv[0] || cur[1] != prv[1]) atomicOr(badmask + sg / 64, 1ull << (sg % 64));
 }
 
-// serial repair from the first mismatching segment (a no-op when every segment merged), then
-// the block's end state
+__device__ inline long pll_next_bad(const unsigned long long *mask, long from, long nseg)
+{
+    for (long wd = from / 64; wd * 64 < nseg; wd++) {
+        unsigned long long m = mask[wd];
+        if (wd == from / 64) m &= ~0ull << (from % 64);
+        if (m) {
+            const long sg = wd * 64 + __ffsll(static_cast<long long>(m)) - 1;
+            return sg < nseg ? sg : nseg;
+        }
+    }
+    return nseg;
+}
+
+// Serial repair (a no-op when every segment merged): from each mismatching segment walk the
+// recurrence from the true state until it is again bit-identical to what the next lane started
+// from -- from there on that lane's (and its successors') results are the serial ones.  Then
+// publish the block's end state.
 __global__ void pll_repair_kernel(const float *__restrict__ in, long n, float *__restrict__ out, float *__restrict__ state,
-                                  PllCoef c, int L, long nseg, const float *__restrict__ seg,
-                                  const unsigned long long *__restrict__ first_bad, unsigned *__restrict__ n_repaired)
+                                  PllCoef c, int L, long nseg, float *__restrict__ seg,
+                                  const unsigned long long *__restrict__ badmask, unsigned *__restrict__ n_repaired)
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    const unsigned long long fb = *first_bad;
-    if (fb >= static_cast<unsigned long long>(nseg)) {
-        PllState e = load_state(seg + (nseg - 1) * 16);
-        store_state(state, e);
-        return;
+    long sg = pll_next_bad(badmask, 1, nseg);
+    unsigned repaired = 0;
+    while (sg < nseg) {
+        PllState s = load_state(seg + (sg - 1) * 16);   // true state at the start of segment sg
+        bool merged = false;
+        while (!merged && sg < nseg) {
+            const long a = sg * L, b = a + L < n ? a + L : n;
+            for (long k = a; k < b; k++) {
+                pll_step<true>(s, in[k], c);
+                out[k + 1] = s.last;
+            }
+            store_state(seg + sg * 16, s);
+            repaired++;
+            sg++;
+            if (sg < nseg) {
+                const unsigned *nx = reinterpret_cast<const unsigned *>(seg + sg * 16 + 8);
+                merged = nx[0] == __float_as_uint(s.integ) && nx[1] == __float_as_uint(s.phase);
+            }
+        }
+        // lane sg started from the true state: it and its successors are valid up to the next mark
+        sg = pll_next_bad(badmask, sg + 1, nseg);
     }
-    PllState s = load_state(seg + (fb - 1) * 16);       // fb >= 1: segment 0 starts from the true state
-    for (long k = static_cast<long>(fb) * L; k < n; k++) {
-        pll_step<true>(s, in[k], c);
-        out[k + 1] = s.last;
-    }
-    store_state(state, s);
-    if (n_repaired) *n_repaired += 1;
+    PllState e = load_state(seg + (nseg - 1) * 16);
+    store_state(state, e);
+    if (n_repaired && repaired) atomicAdd(n_repaired, repaired);
 }
 
 PllCoef make_coef(float freq, float Fs, float ncoScale, float phaseAdjust, float normBandwidth)
@@ -200,7 +228,11 @@ int k_fm_pll(const float *d_in, size_t n, float *d_out, float *d_state, float fr
     return FMRX_OK;
 }
 
-size_t pll_parallel_scratch_floats(size_t n) { return (n / kPllSegment + 2) * 16 + 8; }
+size_t pll_parallel_scratch_floats(size_t n)
+{
+    const size_t nseg = n / kPllSegment + 2;
+    return 8 + nseg * 16 + 2 * (nseg / 64 + 2);
+}
 
 int k_fm_pll_parallel(const float *d_in, size_t n, float *d_out, float *d_state, float freq, float Fs, float ncoScale,
                       float phaseAdjust, float normBandwidth, float *d_scratch, hipStream_t s)
@@ -210,19 +242,19 @@ int k_fm_pll_parallel(const float *d_in, size_t n, float *d_out, float *d_state,
         return k_fm_pll(d_in, n, d_out, d_state, freq, Fs, ncoScale, phaseAdjust, normBandwidth, 1, s);
     const PllCoef c = make_coef(freq, Fs, ncoScale, phaseAdjust, normBandwidth);
     const long nseg = static_cast<long>((n + L - 1) / L);
-    // scratch: [0..1] first_bad (u64), [2] repair counter (u32), [8..] per-segment records
-    unsigned long long *first_bad = reinterpret_cast<unsigned long long *>(d_scratch);
+    // scratch: [2] repaired-segment counter (u32, diagnostic), [8..] per-segment records, then the mismatch bitmask
     unsigned *n_repaired = reinterpret_cast<unsigned *>(d_scratch + 2);
     float *seg = d_scratch + 8;
-    FMRX_HIP(hipMemsetAsync(first_bad, 0xFF, sizeof(unsigned long long), s));
+    unsigned long long *badmask = reinterpret_cast<unsigned long long *>(seg + (nseg + 1) * 16);
+    FMRX_HIP(hipMemsetAsync(badmask, 0, (nseg / 64 + 1) * sizeof(unsigned long long), s));
     const unsigned grid = static_cast<unsigned>((nseg + 63) / 64);
     hipLaunchKernelGGL(pll_segments_kernel, dim3(grid), dim3(64), 0, s, d_in, static_cast<long>(n), d_out, d_state, c, L, W,
                        nseg, seg);
     FMRX_LAUNCH_CHECK("pll_segments");
-    hipLaunchKernelGGL(pll_check_kernel, dim3(grid), dim3(64), 0, s, seg, nseg, first_bad);
+    hipLaunchKernelGGL(pll_check_kernel, dim3(grid), dim3(64), 0, s, seg, nseg, badmask);
     FMRX_LAUNCH_CHECK("pll_check");
     hipLaunchKernelGGL(pll_repair_kernel, dim3(1), dim3(64), 0, s, d_in, static_cast<long>(n), d_out, d_state, c, L, nseg, seg,
-                       first_bad, n_repaired);
+                       badmask, n_repaired);
     FMRX_LAUNCH_CHECK("pll_repair");
     return FMRX_OK;
 }

@@ -27,9 +27,11 @@ for mode in range(4):
     for ch in (1, 2):
         p = fmrx.modeParams(mode)
         per_blk = {0: 20, 1: 20, 2: 18, 3: 15}[mode] * p.block_bytes          # ~1M-sample blocks aligned to the mode's rules
-        nb = BM if ch == 1 else BS
-        iq = torch.from_numpy(synth.synth_fm_u8(per_blk // 2 * min(nb, 4), p.rf_Fs, seed=0x3D74 + mode)).cuda()
-        iq = iq.repeat(max(nb // min(nb, 4), 1))
+        nb = max((BM if ch == 1 else BS) // 3 * 3, 3)
+        # 3 blocks are a whole number of the multiplex's 1 ms periods in every mode, so tiling them (and
+        # wrapping from the end of a step to the start of the next) keeps the pilot phase continuous
+        iq = torch.from_numpy(synth.synth_fm_u8(per_blk // 2 * 3, p.rf_Fs, seed=0x3D74 + mode)).cuda()
+        iq = iq.repeat(nb // 3)
         n_bytes = iq.numel()
         pl = fmrx.Pipeline(mode, ch, max_block_bytes=n_bytes)
         na = pl.n_audio(n_bytes)
