@@ -218,6 +218,13 @@ FMRX_API int fmrx_pipeline_set_profiling(fmrx_pipeline *pl, int on);
  * write them to memory.  on = 1 makes it also store them so that
  * FMRX_TAP_IF_I / FMRX_TAP_IF_Q can be read (diagnostics; default 0). */
 FMRX_API int fmrx_pipeline_set_keep_intermediates(fmrx_pipeline *pl, int on);
+/* Stereo only.  The pilot PLL (fmPLL, src/filter.cpp:32-80) runs parallel in time
+ * (segments with warm-up, verified against the neighbouring segment, serial repair
+ * where the loop was not locked).  Cumulative since creation: segments that had to
+ * be re-run serially, and the largest phase / integrator difference accepted as
+ * "merged" at a segment boundary. */
+FMRX_API int fmrx_pipeline_pll_diagnostics(fmrx_pipeline *pl, unsigned *repaired_segments, float *max_dphase,
+                                           float *max_dinteg);
 /* force the parameter-generic kernels (1) or allow the specialised ones (0) */
 FMRX_API int fmrx_pipeline_set_force_generic(fmrx_pipeline *pl, int on);
 

@@ -122,6 +122,7 @@ _sig("fmrx_pipeline_timing_sum", [_vp, _f32p, C.POINTER(_int), _int])
 _sig("fmrx_pipeline_set_profiling", [_vp, _int])
 _sig("fmrx_pipeline_set_force_generic", [_vp, _int])
 _sig("fmrx_pipeline_set_keep_intermediates", [_vp, _int])
+_sig("fmrx_pipeline_pll_diagnostics", [_vp, C.POINTER(_uint), C.POINTER(_flt), C.POINTER(_flt)])
 _sig("fmrx_fe_fir_decim_u8", [_u8p, _sz, _f32p, _sz, _uint, _vp, _vp, _vp, _int])
 _sig("fmrx_fe_plan_create", [C.POINTER(_vp), _f32p, _sz, _uint])
 _sig("fmrx_fe_plan_destroy", [_vp])
@@ -347,6 +348,12 @@ class Pipeline:
     def set_keep_intermediates(self, on=True):
         """Also store the IF I/Q stream (read_tap('if_i'/'if_q')); the fused front end skips it by default."""
         _check(lib.fmrx_pipeline_set_keep_intermediates(self._h, int(on)))
+
+    def pll_diagnostics(self):
+        """(segments repaired serially, max accepted |dphase|, max accepted |dinteg|) of the parallel PLL."""
+        r, dp, di = _uint(0), _flt(0), _flt(0)
+        _check(lib.fmrx_pipeline_pll_diagnostics(self._h, C.byref(r), C.byref(dp), C.byref(di)))
+        return r.value, dp.value, di.value
 
     def set_force_generic(self, on=True):
         _check(lib.fmrx_pipeline_set_force_generic(self._h, int(on)))

@@ -139,14 +139,21 @@ __global__ void pll_segments_kernel(const float *__restrict__ in, long n, float 
     store_state(seg + sg * 16, s);
 }
 
-// mark every segment whose start state is not, bit for bit, its predecessor's end state
-__global__ void pll_check_kernel(const float *__restrict__ seg, long nseg, unsigned long long *__restrict__ badmask)
+// mark every segment whose start state differs from its predecessor's end state by more than the
+// merge tolerance; record the largest differences seen among the accepted ones (diagnostics)
+__global__ void pll_check_kernel(const float *__restrict__ seg, long nseg, unsigned long long *__restrict__ badmask,
+                                 float tol_phase, float tol_integ, unsigned *__restrict__ diag)
 {
     const long sg = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (sg < 1 || sg >= nseg) return;
-    const unsigned *cur = reinterpret_cast<const unsigned *>(seg + sg * 16 + 8);
-    const unsigned *prv = reinterpret_cast<const unsigned *>(seg + (sg - 1) * 16);
-    if (cur[0] != prv[0] || cur[1] != prv[1]) atomicOr(badmask + sg / 64, 1ull << (sg % 64));
+    const float di = fabsf(seg[sg * 16 + 8] - seg[(sg - 1) * 16 + 0]);
+    const float dp = fabsf(seg[sg * 16 + 9] - seg[(sg - 1) * 16 + 1]);
+    if (!(dp <= tol_phase && di <= tol_integ)) {
+        atomicOr(badmask + sg / 64, 1ull << (sg % 64));
+    } else {
+        atomicMax(diag + 3, __float_as_uint(dp));   // non-negative floats order like their bit patterns
+        atomicMax(diag + 4, __float_as_uint(di));
+    }
 }
 
 __device__ inline long pll_next_bad(const unsigned long long *mask, long from, long nseg)
@@ -168,7 +175,8 @@ __device__ inline long pll_next_bad(const unsigned long long *mask, long from, l
 // publish the block's end state.
 __global__ void pll_repair_kernel(const float *__restrict__ in, long n, float *__restrict__ out, float *__restrict__ state,
                                   PllCoef c, int L, long nseg, float *__restrict__ seg,
-                                  const unsigned long long *__restrict__ badmask, unsigned *__restrict__ n_repaired)
+                                  const unsigned long long *__restrict__ badmask, float tol_phase, float tol_integ,
+                                  unsigned *__restrict__ n_repaired)
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     long sg = pll_next_bad(badmask, 1, nseg);
@@ -185,10 +193,8 @@ __global__ void pll_repair_kernel(const float *__restrict__ in, long n, float *_
             store_state(seg + sg * 16, s);
             repaired++;
             sg++;
-            if (sg < nseg) {
-                const unsigned *nx = reinterpret_cast<const unsigned *>(seg + sg * 16 + 8);
-                merged = nx[0] == __float_as_uint(s.integ) && nx[1] == __float_as_uint(s.phase);
-            }
+            if (sg < nseg)
+                merged = fabsf(seg[sg * 16 + 9] - s.phase) <= tol_phase && fabsf(seg[sg * 16 + 8] - s.integ) <= tol_integ;
         }
         // lane sg started from the true state: it and its successors are valid up to the next mark
         sg = pll_next_bad(badmask, sg + 1, nseg);
@@ -251,10 +257,11 @@ int k_fm_pll_parallel(const float *d_in, size_t n, float *d_out, float *d_state,
     hipLaunchKernelGGL(pll_segments_kernel, dim3(grid), dim3(64), 0, s, d_in, static_cast<long>(n), d_out, d_state, c, L, W,
                        nseg, seg);
     FMRX_LAUNCH_CHECK("pll_segments");
-    hipLaunchKernelGGL(pll_check_kernel, dim3(grid), dim3(64), 0, s, seg, nseg, badmask);
+    hipLaunchKernelGGL(pll_check_kernel, dim3(grid), dim3(64), 0, s, seg, nseg, badmask, kPllTolPhase, kPllTolInteg,
+                       reinterpret_cast<unsigned *>(d_scratch));
     FMRX_LAUNCH_CHECK("pll_check");
     hipLaunchKernelGGL(pll_repair_kernel, dim3(1), dim3(64), 0, s, d_in, static_cast<long>(n), d_out, d_state, c, L, nseg, seg,
-                       badmask, n_repaired);
+                       badmask, kPllTolPhase, kPllTolInteg, n_repaired);
     FMRX_LAUNCH_CHECK("pll_repair");
     return FMRX_OK;
 }

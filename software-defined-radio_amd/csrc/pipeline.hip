@@ -286,6 +286,20 @@ int fmrx_pipeline_set_profiling(fmrx_pipeline *pl, int on)
     return FMRX_OK;
 }
 
+int fmrx_pipeline_pll_diagnostics(fmrx_pipeline *pl, unsigned *repaired_segments, float *max_dphase, float *max_dinteg)
+{
+    if (!pl) return fail(FMRX_EINVAL, "null handle");
+    if (pl->channels != 2) return fail(FMRX_EINVAL, "pll_diagnostics: not a stereo pipeline");
+    FMRX_HIP(hipSetDevice(pl->device));
+    FMRX_HIP(hipDeviceSynchronize());
+    unsigned hdr[8];
+    FMRX_HIP(hipMemcpy(hdr, pl->pll_scratch.p, sizeof(hdr), hipMemcpyDeviceToHost));
+    if (repaired_segments) *repaired_segments = hdr[2];
+    if (max_dphase) std::memcpy(max_dphase, &hdr[3], sizeof(float));
+    if (max_dinteg) std::memcpy(max_dinteg, &hdr[4], sizeof(float));
+    return FMRX_OK;
+}
+
 int fmrx_pipeline_set_keep_intermediates(fmrx_pipeline *pl, int on)
 {
     if (!pl) return fail(FMRX_EINVAL, "null handle");
