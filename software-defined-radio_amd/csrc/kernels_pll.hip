@@ -23,9 +23,12 @@
 //    state is float32 two trajectories that come close enough become BIT-IDENTICAL
 //    (the difference drops under half an ulp and rounds away).  So the block is
 //    cut into segments of L samples, one lane each; a lane starts W samples early
-//    from the block's initial state extrapolated along the integrator (phase
-//    advances by integ per sample in lock) and runs the same recurrence; after
-//    the warm-up it has (normally exactly) merged with the serial trajectory.
+//    from the block's initial state (phase extrapolated with the slope observed
+//    over the previous block: a locked loop's phase is constant when the pilot is
+//    on frequency and drifts linearly when it is not) and runs the same recurrence; after
+//    the warm-up it has merged with the serial trajectory -- as far as the loop
+//    itself can tell: its phase detector only sees trigArg rounded to float32
+//    (~1e-3 rad at 1e4 rad), so "merged" means equal to within that grid.
 //    Nothing is assumed: a second kernel compares, for every segment, the state a
 //    lane had at its segment start with the state its predecessor ended on, and a
 //    third walks the recurrence serially from every segment that does not match
@@ -108,7 +111,7 @@ __global__ void pll_serial_kernel(const float *__restrict__ in, size_t n, float 
 // seg[s*16 + 8..9]  (integ, phase) this lane had at the START of segment s (after its warm-up)
 __global__ void pll_segments_kernel(const float *__restrict__ in, long n, float *__restrict__ out,
                                     const float *__restrict__ state, PllCoef c, int L, int W, long nseg,
-                                    float *__restrict__ seg)
+                                    float *__restrict__ seg, const float *__restrict__ hdr)
 {
     const long sg = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (sg >= nseg) return;
@@ -118,9 +121,10 @@ __global__ void pll_segments_kernel(const float *__restrict__ in, long n, float 
     PllState s = s0;
     long k = 0;
     if (a > W) {
-        // warm start W samples early: in lock the phase advances by `integ` per sample
+        // warm start W samples early; hdr[5..7] = {phase at the start of the previous call, its length, valid}
         k = a - W;
-        s.phase = s0.phase + s0.integ * static_cast<float>(k);
+        const float slope = hdr[7] != 0.0f ? (s0.phase - hdr[5]) / hdr[6] : 0.0f;
+        s.phase = s0.phase + slope * static_cast<float>(k);
         s.off = s0.off + static_cast<float>(k);
         const float trigArg = static_cast<float>(c.w * static_cast<double>(s.off) + static_cast<double>(s.phase));
         const double rev = static_cast<double>(trigArg) * 0.15915494309189533577;
@@ -176,7 +180,7 @@ __device__ inline long pll_next_bad(const unsigned long long *mask, long from, l
 __global__ void pll_repair_kernel(const float *__restrict__ in, long n, float *__restrict__ out, float *__restrict__ state,
                                   PllCoef c, int L, long nseg, float *__restrict__ seg,
                                   const unsigned long long *__restrict__ badmask, float tol_phase, float tol_integ,
-                                  unsigned *__restrict__ n_repaired)
+                                  unsigned *__restrict__ n_repaired, float *__restrict__ hdr)
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     long sg = pll_next_bad(badmask, 1, nseg);
@@ -199,6 +203,10 @@ __global__ void pll_repair_kernel(const float *__restrict__ in, long n, float *_
         // lane sg started from the true state: it and its successors are valid up to the next mark
         sg = pll_next_bad(badmask, sg + 1, nseg);
     }
+    // remember where this call's phase started, for the next call's extrapolation
+    hdr[5] = state[1];
+    hdr[6] = static_cast<float>(n);
+    hdr[7] = 1.0f;
     PllState e = load_state(seg + (nseg - 1) * 16);
     store_state(state, e);
     if (n_repaired && repaired) atomicAdd(n_repaired, repaired);
@@ -248,20 +256,21 @@ int k_fm_pll_parallel(const float *d_in, size_t n, float *d_out, float *d_state,
         return k_fm_pll(d_in, n, d_out, d_state, freq, Fs, ncoScale, phaseAdjust, normBandwidth, 1, s);
     const PllCoef c = make_coef(freq, Fs, ncoScale, phaseAdjust, normBandwidth);
     const long nseg = static_cast<long>((n + L - 1) / L);
-    // scratch: [2] repaired-segment counter (u32, diagnostic), [8..] per-segment records, then the mismatch bitmask
+    // scratch: [2] repaired-segment counter (u32), [3],[4] largest accepted |dphase|,|dinteg| (diagnostics),
+    // [5..7] previous call's start phase / length / valid; [8..] per-segment records, then the mismatch bitmask
     unsigned *n_repaired = reinterpret_cast<unsigned *>(d_scratch + 2);
     float *seg = d_scratch + 8;
     unsigned long long *badmask = reinterpret_cast<unsigned long long *>(seg + (nseg + 1) * 16);
     FMRX_HIP(hipMemsetAsync(badmask, 0, (nseg / 64 + 1) * sizeof(unsigned long long), s));
     const unsigned grid = static_cast<unsigned>((nseg + 63) / 64);
     hipLaunchKernelGGL(pll_segments_kernel, dim3(grid), dim3(64), 0, s, d_in, static_cast<long>(n), d_out, d_state, c, L, W,
-                       nseg, seg);
+                       nseg, seg, d_scratch);
     FMRX_LAUNCH_CHECK("pll_segments");
     hipLaunchKernelGGL(pll_check_kernel, dim3(grid), dim3(64), 0, s, seg, nseg, badmask, kPllTolPhase, kPllTolInteg,
                        reinterpret_cast<unsigned *>(d_scratch));
     FMRX_LAUNCH_CHECK("pll_check");
     hipLaunchKernelGGL(pll_repair_kernel, dim3(1), dim3(64), 0, s, d_in, static_cast<long>(n), d_out, d_state, c, L, nseg, seg,
-                       badmask, kPllTolPhase, kPllTolInteg, n_repaired);
+                       badmask, kPllTolPhase, kPllTolInteg, n_repaired, d_scratch);
     FMRX_LAUNCH_CHECK("pll_repair");
     return FMRX_OK;
 }

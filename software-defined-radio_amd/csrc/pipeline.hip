@@ -131,6 +131,7 @@ int reset_state(fmrx_pipeline *pl)
         FMRX_HIP(hipMemsetAsync(pl->mixer.p, 0, pl->Hm * sizeof(float), s));
         const float init[6] = {0.0f, 0.0f, 1.0f, 0.0f, 1.0f, 0.0f};  // src/project.cpp:458
         FMRX_HIP(hipMemcpyAsync(pl->pll_state.p, init, sizeof(init), hipMemcpyHostToDevice, s));
+        FMRX_HIP(hipMemsetAsync(pl->pll_scratch.p + 5, 0, 3 * sizeof(float), s));   // no phase-slope history yet
     }
     FMRX_HIP(hipStreamSynchronize(s));
     pl->fe_cur = pl->prev_cur = 0;
@@ -581,6 +582,7 @@ int fmrx_pipeline_set_state(fmrx_pipeline *pl, const float *state, size_t n)
     FMRX_HIP(hipMemcpy(pl->demod.p, dh.data(), pl->Hd * sizeof(float), hipMemcpyHostToDevice));
     pl->prev_override = true;   // the fused front end would otherwise recompute IF[-1] from the byte history
     pl->pll_warm = false;
+    if (pl->channels == 2) FMRX_HIP(hipMemset(pl->pll_scratch.p + 5, 0, 3 * sizeof(float)));
     return FMRX_OK;
 }
 
