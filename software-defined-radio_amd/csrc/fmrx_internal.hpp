@@ -115,6 +115,17 @@ int resample_plan_init(ResamplePlan &pl, const float *h, int taps, int decim, in
 int resample_launch(const ResamplePlan &pl, const float *d_x, size_t n_in, int delay, float *d_y, hipStream_t stream,
                     bool force_generic);
 
+// ---- stereo band-pass pair (kernels_stereo.hip) ------------------------------------
+struct BpfPairPlan {
+    int taps = 0;
+    bool fast = false;
+    DevBuf<float> table;        // interleaved reversed tap pairs (h_stereo, h_carrier)
+    DevBuf<float> h_st, h_car;  // plain taps (generic path)
+};
+int bpf_pair_plan_init(BpfPairPlan &pl, const float *h_stereo, const float *h_carrier, int taps);
+int bpf_pair_launch(const BpfPairPlan &pl, const float *d_x, size_t n, float *d_st, float *d_car, hipStream_t stream,
+                    bool force_generic);
+
 // ---- generic kernels (kernels_generic.hip) ----------------------------------
 // y[k] = sum_{n<taps} h[n]*x[decim*k - n], sequential mul+add in n (bit-compatible
 // with the reference's evaluation order).  x[-(taps-1)..-1] must be readable.

@@ -1,0 +1,172 @@
+// kernels_stereo.hip -- the two band-pass filters of the stereo path in one pass.
+//
+// Replaces the two convolveBlockFIR calls of RF_STEREO (src/project.cpp:202, 207 ->
+// src/filter.cpp:133-154): stereo_filt = demod * h(22-54 kHz), carrier_filt =
+// demod * h(18.5-19.5 kHz), no decimation, same input.  The two filters ride in the
+// two halves of v_pk_fma_f32: acc(st, car) += x * (h_st[n], h_car[n]) with the tap
+// PAIR as a wave-uniform SGPR operand and x broadcast to both halves.  A thread
+// produces 8 consecutive outputs from a register-resident window of 8+T-1 samples
+// read straight from global memory (27 x 16 B at T = 101; lanes are 32 B apart, so a
+// wave's loads walk 2.4 KB of contiguous, L1-resident data) -- no LDS, no barrier.
+// ~101 packed FMAs per IF sample for both filters.
+//
+// Numerics: one FMA per tap, taps ascending in n as the reference does; differs
+// from its separate multiply/add by float32 rounding only (generic kernel = exact).
+#include "fmrx_internal.hpp"
+
+namespace fmrx {
+
+namespace {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+constexpr int kPC = 8;   // tap pairs per scalar load (16 SGPRs)
+
+#define FMRX_PAIRS_ISSUE(hp, table, off) asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(hp) : "s"(table), "i"(off))
+#define FMRX_PAIRS_WAIT(hp) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(hp))
+
+template <int T, int R, int G>
+__device__ __forceinline__ void bpf_step(const float (&w)[R + T - 1 + 3], const float *__restrict__ table, f2 (&acc)[R],
+                                         f16v &hA, f16v &hB)
+{
+    constexpr int NG = (T + kPC - 1) / kPC;
+    if constexpr (G < NG) {
+        // table entry m = (h_st[T-1-m], h_car[T-1-m]): window sample i = r + m meets output r
+        float hq[2 * kPC];
+        if constexpr (G % 2 == 0) {
+            FMRX_PAIRS_WAIT(hA);
+            if constexpr (G + 1 < NG) FMRX_PAIRS_ISSUE(hB, table, (G + 1) * kPC * 8);
+#pragma unroll
+            for (int k = 0; k < 2 * kPC; k++) hq[k] = hA[k];
+        } else {
+            FMRX_PAIRS_WAIT(hB);
+            if constexpr (G + 1 < NG) FMRX_PAIRS_ISSUE(hA, table, (G + 1) * kPC * 8);
+#pragma unroll
+            for (int k = 0; k < 2 * kPC; k++) hq[k] = hB[k];
+        }
+#pragma unroll
+        for (int s = 0; s < R + kPC - 1; s++) {
+            const int i = G * kPC + s;
+            if (i < R + T - 1) {
+                const float x = w[i];
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int m = i - r;
+                    if (m >= G * kPC && m < (G + 1) * kPC && m < T)
+                        acc[r] = __builtin_elementwise_fma((f2){x, x}, (f2){hq[2 * (m - G * kPC)], hq[2 * (m - G * kPC) + 1]}, acc[r]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) asm volatile("" : "+v"(acc[r]));
+        bpf_step<T, R, G + 1>(w, table, acc, hA, hB);
+    }
+}
+
+template <int T, int R, int NT>
+__global__ __launch_bounds__(NT) void bpf_pair_kernel(const float *__restrict__ x, long n, const float *__restrict__ table,
+                                                       float *__restrict__ y_st, float *__restrict__ y_car)
+{
+    // x is 16-byte aligned at index 0 and has >= T-1+3 readable samples of history in front
+    const long k0 = (static_cast<long>(blockIdx.x) * NT + threadIdx.x) * R;   // first output of this thread
+    if (k0 >= n) return;
+    constexpr int LEAD = (4 - (T - 1) % 4) % 4;          // so that the window starts on a 16-byte boundary
+    constexpr int NW = R + T - 1 + LEAD;                 // floats loaded
+    static_assert(NW % 4 == 0 && LEAD <= 3, "window must be whole 16-byte chunks");
+    const f4 *src = reinterpret_cast<const f4 *>(x + k0 - (T - 1) - LEAD);
+    float wl[NW];
+#pragma unroll
+    for (int i = 0; i < NW / 4; i++) {
+        const f4 v = src[i];
+        wl[4 * i] = v.x;
+        wl[4 * i + 1] = v.y;
+        wl[4 * i + 2] = v.z;
+        wl[4 * i + 3] = v.w;
+    }
+    float w[R + T - 1 + 3];
+#pragma unroll
+    for (int i = 0; i < R + T - 1; i++) w[i] = wl[i + LEAD];
+    f2 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = (f2){0.0f, 0.0f};
+    f16v hA, hB;
+    FMRX_PAIRS_ISSUE(hA, table, 0);
+    bpf_step<T, R, 0>(w, table, acc, hA, hB);
+    if (k0 + R <= n) {
+        f4 *ds = reinterpret_cast<f4 *>(y_st + k0), *dc = reinterpret_cast<f4 *>(y_car + k0);
+#pragma unroll
+        for (int r = 0; r < R; r += 4) {
+            ds[r / 4] = (f4){acc[r].x, acc[r + 1].x, acc[r + 2].x, acc[r + 3].x};
+            dc[r / 4] = (f4){acc[r].y, acc[r + 1].y, acc[r + 2].y, acc[r + 3].y};
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if (k0 + r < n) {
+                y_st[k0 + r] = acc[r].x;
+                y_car[k0 + r] = acc[r].y;
+            }
+    }
+}
+
+template <int T>
+int launch(const BpfPairPlan &pl, const float *d_x, size_t n, float *d_st, float *d_car, hipStream_t stream)
+{
+    constexpr int R = 8, NT = 256;
+    const unsigned grid = static_cast<unsigned>((n + NT * R - 1) / (NT * R));
+    hipLaunchKernelGGL((bpf_pair_kernel<T, R, NT>), dim3(grid), dim3(NT), 0, stream, d_x, static_cast<long>(n), pl.table.p,
+                       d_st, d_car);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FMRX_EHIP, "launch bpf_pair_kernel<%d>: %s", T, hipGetErrorString(e));
+    return FMRX_OK;
+}
+
+// stereo tap counts in the reference: 13 (project.cpp:429), 151 (model), 101 (the report's final choice)
+#define FMRX_BPF_CASES(X) X(13) X(101) X(151)
+
+}  // namespace
+
+int bpf_pair_plan_init(BpfPairPlan &pl, const float *h_stereo, const float *h_carrier, int taps)
+{
+    pl.taps = taps;
+    pl.fast = false;
+    FMRX_TRY(pl.h_st.alloc(taps));
+    FMRX_TRY(pl.h_car.alloc(taps));
+    FMRX_HIP(hipMemcpy(pl.h_st.p, h_stereo, taps * sizeof(float), hipMemcpyHostToDevice));
+    FMRX_HIP(hipMemcpy(pl.h_car.p, h_carrier, taps * sizeof(float), hipMemcpyHostToDevice));
+#define X(T_) \
+    if (taps == T_) pl.fast = true;
+    FMRX_BPF_CASES(X)
+#undef X
+    if (pl.fast) {
+        const int ng = (taps + kPC - 1) / kPC;
+        std::vector<float> tab(static_cast<size_t>(ng) * kPC * 2, 0.0f);
+        for (int m = 0; m < taps; m++) {
+            tab[2 * m] = h_stereo[taps - 1 - m];
+            tab[2 * m + 1] = h_carrier[taps - 1 - m];
+        }
+        FMRX_TRY(pl.table.alloc(tab.size()));
+        FMRX_HIP(hipMemcpy(pl.table.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return FMRX_OK;
+}
+
+// d_x: block start (16-byte aligned), taps-1+3 samples of history in front
+int bpf_pair_launch(const BpfPairPlan &pl, const float *d_x, size_t n, float *d_st, float *d_car, hipStream_t stream,
+                    bool force_generic)
+{
+    if (n == 0) return FMRX_OK;
+    if (pl.fast && !force_generic && reinterpret_cast<uintptr_t>(d_x) % 16 == 0 && reinterpret_cast<uintptr_t>(d_st) % 16 == 0 &&
+        reinterpret_cast<uintptr_t>(d_car) % 16 == 0) {
+#define X(T_) \
+    if (pl.taps == T_) return launch<T_>(pl, d_x, n, d_st, d_car, stream);
+        FMRX_BPF_CASES(X)
+#undef X
+    }
+    FMRX_TRY(k_fir_generic(d_x, n, pl.h_st.p, pl.taps, 1, d_st, stream));
+    return k_fir_generic(d_x, n, pl.h_car.p, pl.taps, 1, d_car, stream);
+}
+
+}  // namespace fmrx

@@ -44,7 +44,7 @@ struct fmrx_pipeline {
     FePlan fe;
     AudioPlan audio;
     ResamplePlan rs;           // resampler (modes 2, 3)
-    DevBuf<float> h_carrier, h_stereo;
+    BpfPairPlan bpf_plan;      // stereo + pilot band-pass filters
 
     DevBuf<uint8_t> in;
     DevBuf<uint8_t> fe_hist[2];
@@ -189,7 +189,7 @@ int fmrx_pipeline_create(fmrx_pipeline **out, const fmrx_params *p, int channels
     pl->St = channels == 2 ? p->stereo_taps : 0;
     pl->delay = channels == 2 ? (p->stereo_taps - 1) / 2 : 0;
     pl->Hd = pl->Ha + pl->delay;
-    if (channels == 2 && pl->St - 1 > pl->Hd) pl->Hd = pl->St - 1;
+    if (channels == 2 && pl->St - 1 + 3 > pl->Hd) pl->Hd = pl->St - 1 + 3;   // the band-pass pair kernel reads 16-byte chunks
     pl->Hd = (pl->Hd + 3) / 4 * 4 + 4;   // the specialised audio kernel loads aligned 16-byte chunks
     pl->Hm = (pl->Ha + 3) / 4 * 4 + 4;
 
@@ -223,13 +223,10 @@ int fmrx_pipeline_create(fmrx_pipeline **out, const fmrx_params *p, int channels
         FMRX_TRY(pl->tmp_hist.alloc(pl->Hd + pl->Hm + 16));
         FMRX_TRY(pl->mono.alloc(n_au));
         if (channels == 2) {
-            h.resize(p->stereo_taps);
-            design_bpf(static_cast<float>(p->if_Fs), 18.5e3f, 19.5e3f, p->stereo_taps, h.data());
-            FMRX_TRY(pl->h_carrier.alloc(p->stereo_taps));
-            FMRX_HIP(hipMemcpy(pl->h_carrier.p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
-            design_bpf(static_cast<float>(p->if_Fs), 22e3f, 54e3f, p->stereo_taps, h.data());
-            FMRX_TRY(pl->h_stereo.alloc(p->stereo_taps));
-            FMRX_HIP(hipMemcpy(pl->h_stereo.p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+            std::vector<float> hc(p->stereo_taps), hs(p->stereo_taps);
+            design_bpf(static_cast<float>(p->if_Fs), 18.5e3f, 19.5e3f, p->stereo_taps, hc.data());
+            design_bpf(static_cast<float>(p->if_Fs), 22e3f, 54e3f, p->stereo_taps, hs.data());
+            FMRX_TRY(bpf_pair_plan_init(pl->bpf_plan, hs.data(), hc.data(), p->stereo_taps));
             FMRX_TRY(pl->carrier.alloc(n_if + 16));
             FMRX_TRY(pl->bpf.alloc(n_if + 16));
             FMRX_TRY(pl->pll.alloc(n_if + 17));
@@ -394,8 +391,7 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
         float *mixer = pl->mixer.p + pl->Hm;
         FMRX_TRY(audio_stage(pl, demod, n_if, pl->delay, pl->mono.p, s));  // all-pass = index offset
         if (pl->profiling) FMRX_HIP(hipEventRecord(ev[2], s));
-        FMRX_TRY(k_fir_generic(demod, n_if, pl->h_stereo.p, pl->St, 1, pl->bpf.p, s));
-        FMRX_TRY(k_fir_generic(demod, n_if, pl->h_carrier.p, pl->St, 1, pl->carrier.p, s));
+        FMRX_TRY(bpf_pair_launch(pl->bpf_plan, demod, n_if, pl->bpf.p, pl->carrier.p, s, pl->force_generic));
         if (pl->force_generic)
             FMRX_TRY(k_fm_pll(pl->carrier.p, n_if, pl->pll.p, pl->pll_state.p, 19e3f, static_cast<float>(p.if_Fs), 2.0f,
                               0.0f, 0.01f, 0, s));
