@@ -143,13 +143,25 @@ __global__ void pll_segments_kernel(const float *__restrict__ in, long n, float 
     store_state(seg + sg * 16, s);
 }
 
+// The loop cannot tell phases apart that round to the same float32 trigArg, so the merge
+// tolerance follows that grid: base + 2 ulp(trigArg) at the end of the block (ulp grows from 1e-3
+// at 1e4 rad to 0.25 at 3e6 rad -- the reference's own resolution loss).
+__device__ __forceinline__ float pll_phase_tol(float base, const float *state, long n, const PllCoef &c)
+{
+    const float top = static_cast<float>(c.w * (static_cast<double>(state[5]) + static_cast<double>(n)));
+    const float ulp = __uint_as_float((__float_as_uint(top) & 0x7f800000u)) * 1.1920929e-7f;   // 2^(e-23)
+    return base + 2.0f * ulp;
+}
+
 // mark every segment whose start state differs from its predecessor's end state by more than the
 // merge tolerance; record the largest differences seen among the accepted ones (diagnostics)
 __global__ void pll_check_kernel(const float *__restrict__ seg, long nseg, unsigned long long *__restrict__ badmask,
-                                 float tol_phase, float tol_integ, unsigned *__restrict__ diag)
+                                 float tol_phase_base, float tol_integ, unsigned *__restrict__ diag,
+                                 const float *__restrict__ state, long n, PllCoef c)
 {
     const long sg = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (sg < 1 || sg >= nseg) return;
+    const float tol_phase = pll_phase_tol(tol_phase_base, state, n, c);
     const float di = fabsf(seg[sg * 16 + 8] - seg[(sg - 1) * 16 + 0]);
     const float dp = fabsf(seg[sg * 16 + 9] - seg[(sg - 1) * 16 + 1]);
     if (!(dp <= tol_phase && di <= tol_integ)) {
@@ -179,10 +191,11 @@ __device__ inline long pll_next_bad(const unsigned long long *mask, long from, l
 // publish the block's end state.
 __global__ void pll_repair_kernel(const float *__restrict__ in, long n, float *__restrict__ out, float *__restrict__ state,
                                   PllCoef c, int L, long nseg, float *__restrict__ seg,
-                                  const unsigned long long *__restrict__ badmask, float tol_phase, float tol_integ,
+                                  const unsigned long long *__restrict__ badmask, float tol_phase_base, float tol_integ,
                                   unsigned *__restrict__ n_repaired, float *__restrict__ hdr)
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const float tol_phase = pll_phase_tol(tol_phase_base, state, n, c);
     long sg = pll_next_bad(badmask, 1, nseg);
     unsigned repaired = 0;
     while (sg < nseg) {
@@ -267,7 +280,7 @@ int k_fm_pll_parallel(const float *d_in, size_t n, float *d_out, float *d_state,
                        nseg, seg, d_scratch);
     FMRX_LAUNCH_CHECK("pll_segments");
     hipLaunchKernelGGL(pll_check_kernel, dim3(grid), dim3(64), 0, s, seg, nseg, badmask, kPllTolPhase, kPllTolInteg,
-                       reinterpret_cast<unsigned *>(d_scratch));
+                       reinterpret_cast<unsigned *>(d_scratch), d_state, static_cast<long>(n), c);
     FMRX_LAUNCH_CHECK("pll_check");
     hipLaunchKernelGGL(pll_repair_kernel, dim3(1), dim3(64), 0, s, d_in, static_cast<long>(n), d_out, d_state, c, L, nseg, seg,
                        badmask, kPllTolPhase, kPllTolInteg, n_repaired, d_scratch);
