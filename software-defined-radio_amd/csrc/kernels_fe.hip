@@ -131,7 +131,9 @@ __device__ __forceinline__ void fe_step(const uint32_t (&raw)[FeCfg<T, D, R, NT>
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     const int q = i - r;
-                    if (q >= c * kQC && q < (c + 1) * kQC && p + D * q < T) {
+                    // m = p + D*q = T-1 is tap h[0], which the sin^2 window makes exactly 0 (fe_plan_init
+                    // checks it): skipped, 8 FMAs per tile
+                    if (q >= c * kQC && q < (c + 1) * kQC && p + D * q < T - 1) {
                         const float h = hq[q - c * kQC];
                         acc[r] = __builtin_elementwise_fma(xs, (f2){h, h}, acc[r]);  // v_pk_fma_f32
                     }
@@ -417,11 +419,23 @@ __global__ __launch_bounds__(256, (FeWaveCfg<T, D, R>::MINW)) void fe_demod_kern
             pq = po.y;
         }
         float d[R];
+        {
+            // the discriminator of device_math.hpp::demod_fast, written on (I,Q) pairs so that the
+            // squares, the differences and the crossed products are one packed instruction each
+            f2 pz = (f2){pi, pq};
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            d[r] = demod_fast(acc[r].x, acc[r].y, pi, pq);
-            pi = acc[r].x;
-            pq = acc[r].y;
+            for (int r = 0; r < R; r++) {
+                const f2 z = acc[r];
+                const f2 sq = z * z;                                  // (I*I, Q*Q)
+                const float den = sq.x + sq.y;
+                const f2 dz = z - pz;                                 // (I-Ip, Q-Qp)
+                const f2 cr = z * __builtin_shufflevector(dz, dz, 1, 0);   // (I*(Q-Qp), Q*(I-Ip))
+                const float num = cr.x - cr.y;
+                const float sc = den < 8.6736174e-19f ? 1.8446744e19f : 1.0f;
+                const float q = (num * sc) * __builtin_amdgcn_rcpf(den * sc);
+                d[r] = den == 0.0f ? 0.0f : q;
+                pz = z;
+            }
         }
         // interior tile without the optional IF stream: every lane >= 1 stores, 2 x dwordx4 (>= 2 store
         // instructions in any case, which is the safe direction for the counted wait above)
@@ -545,8 +559,10 @@ int fe_plan_init(FePlan &pl, const float *h, int taps, int decim)
     FMRX_TRY(pl.h.alloc(taps));
     FMRX_HIP(hipMemcpy(pl.h.p, h, taps * sizeof(float), hipMemcpyHostToDevice));
     std::vector<float> tab;
+    // the specialised kernels skip tap 0: only for designs whose h[0] is exactly 0 (every
+    // impulseResponseLPF output: its window is sin^2(i*pi/T))
 #define X(T_, D_)                             \
-    if (taps == T_ && decim == D_) {          \
+    if (taps == T_ && decim == D_ && h[0] == 0.0f) { \
         build_table<T_, D_>(h, tab);          \
         pl.fast = true;                       \
     }
