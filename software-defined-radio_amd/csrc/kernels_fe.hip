@@ -1,45 +1,53 @@
-// kernels_fe.hip -- the front-end kernel: raw u8 I/Q -> (u-128)/128 -> T-tap
-// low-pass FIR -> decimate by D, I and Q together, one pass over HBM.
+// kernels_fe.hip -- the front end: raw u8 I/Q -> (u-128)/128 -> T-tap low-pass
+// FIR -> decimate by D (I and Q together) -> FM discriminator, one pass over HBM.
 //
 // Replaces, fused: readStdinBlockData's conversion (src/iofunc.cpp:133), the
-// I/Q split (src/project.cpp:98-105) and the two convolveBlockFastFIR calls of
-// RF_FrontEnd (src/project.cpp:111,121 -> src/filter.cpp:158-188), which are
-// ~90 % of the reference's run time.
+// I/Q split (src/project.cpp:98-105), the two convolveBlockFastFIR calls of
+// RF_FrontEnd (src/project.cpp:111,121 -> src/filter.cpp:158-188) -- ~90 % of
+// the reference's run time -- and fmDemod
+// (src/project.cpp:128 -> src/filter.cpp:248-266).
 //
-// Design (CDNA4 / gfx950, wave64, VALU packed-FP32; no MFMA -- this is a 1-D
-// vector FIR with a 1-column "B matrix"):
+// Three kernels share one arithmetic core (fe_compute):
+//   fe_demod_kernel    the pipeline's kernel: FIR + discriminator, one WAVE per
+//                      tile, LDS-DMA staging, no workgroup barrier; writes demod
+//                      (4/D B per sample) and, on request, the IF stream
+//   fe_fir_kernel_pf   IF-only (behind fmrx_fe_run_dev): persistent workgroups,
+//                      next tile prefetched into registers
+//   fe_fir_kernel      IF-only, one tile per workgroup (baseline; FMRX_FE_VARIANT=1)
 //
-//  * HBM traffic is the algorithmic minimum: every input byte is read once by
-//    a coalesced 16 B/lane load (the T-1 sample halo between neighbouring
-//    tiles is < 0.5 % and L2-resident) and every output float2 written once.
-//    Per complex input sample: 2 B in + 8/D B out (2.8 B at D = 10).
-//  * A workgroup of NT threads stages the raw BYTES of its tile
-//    (D*R*NT + T-1 samples) in LDS -- 41 KB at NT=256, R=8, D=10 -- so the
-//    8-bit data is not inflated before it reaches registers.
+// The core (CDNA4 / gfx950, wave64, VALU packed FP32; no MFMA -- a 1-D FIR has a
+// one-column "B matrix"):
+//
+//  * Bytes stay bytes until the register file: a tile's raw I/Q bytes are staged
+//    in LDS (10 KB per wave tile), never inflated to floats in memory.  HBM
+//    traffic is the algorithmic minimum (PMC: 1.03x): every input byte read once
+//    by a coalesced 16 B/lane access, the T-1 sample halo between tiles is < 2 %
+//    and L2-resident.
 //  * Each thread produces R = 8 CONSECUTIVE outputs.  Its whole input window
-//    (D*(R-1)+T samples = 171 at T=101, D=10) is 22 ds_read_b128 into
-//    registers; every byte is then addressed statically (v_cvt_f32_ubyteN on a
-//    compile-time register), so there is no per-tap address arithmetic at all.
+//    (D*(R-1)+T samples = 171 at T=101, D=10) is 22 ds_read_b128 into registers;
+//    every byte is then addressed statically (v_cvt_f32_i32_sdwa sext(v)
+//    src0_sel:BYTE_n on a compile-time register): no per-tap address arithmetic.
 //  * I and Q ride in the two halves of one v_pk_fma_f32: acc(I,Q) += (xI,xQ)*h.
 //    The tap is a wave-uniform SGPR operand (op_sel picks the half of an SGPR
-//    pair), so taps cost no VGPRs and no LDS bandwidth.
-//  * The computation is ordered by polyphase branch p = j mod D: branch p needs
-//    only ceil(T/D) taps (<= 12 SGPRs, one s_load_dwordx8 + one dwordx4) and
-//    the R+ceil(T/D)-1 window samples j = p + D*i, each converted once per
-//    branch and reused by up to R outputs.  Per 8 outputs: 808 v_pk_fma_f32 +
-//    342 v_cvt (T=101, D=10), i.e. ~70 % of VALU issue is useful FMA.
-//  * (u-128)/128 costs nothing per tap: the staging pass flips the top bit of
-//    every byte (u ^ 0x80 is u-128 as a signed byte; one v_xor per 4 samples,
-//    once per tile), the window bytes are converted with the sign-extending
-//    v_cvt_f32_i32 (SDWA byte select), and the taps are pre-scaled by 1/128
-//    (exact).  Every product h[n]*(u-128)/128 is then the reference's product
-//    bit for bit, silence (u = 128) gives exact zeros, and the rounding error
-//    scales with the signal instead of with the 128 offset.
+//    pair): taps cost no VGPRs and no LDS bandwidth.
+//  * Work is ordered by polyphase branch p = j mod D: branch p needs only
+//    ceil(T/D) taps (<= 12 SGPRs per group, s_load_dwordx8 + dwordx4, double
+//    buffered so the next group loads under this group's FMAs) and the
+//    R+ceil(T/D)-1 window samples j = p + D*i, each converted once per branch and
+//    reused by up to R outputs.  Per 8 outputs: 800 v_pk_fma_f32 + 342 v_cvt +
+//    86 v_xor (T=101, D=10; tap h[0] is exactly 0 and skipped).
+//  * (u-128)/128: the top bit of every byte is flipped once (u ^ 0x80 is u-128
+//    as a signed byte), bytes are converted with sign extension, and the taps are
+//    pre-scaled by 1/128 (exact).  Every product h[n]*(u-128)/128 is then the
+//    reference's product bit for bit, silence (u = 128) gives exact zeros, and
+//    the rounding error scales with the signal, not with the 128 offset.
 //
-// Numerics: one fused multiply-add per tap, taps visited branch by branch
-// instead of n = 0..T-1; the result differs from the reference's sequential
-// multiply/add by a few float32 ulp (tests bound the RMS error; the pipeline's
-// audio stays within 1e-4 RMS of the reference, SURVEY 7.3 "Summation order").
+// Numerics: one fused multiply-add per tap, taps visited branch by branch instead
+// of n = 0..T-1: IF samples differ from the reference's sequential multiply/add
+// by a few float32 ulp (measured 2e-7 relative RMS).  The discriminator keeps the
+// reference's operation order except for the division (v_rcp_f32).  Every output
+// is produced by the same instruction sequence wherever it is computed, so the
+// result does not depend on how the stream is cut into tiles or blocks.
 #include "device_math.hpp"
 #include "fmrx_internal.hpp"
 
