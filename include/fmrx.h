@@ -130,6 +130,15 @@ FMRX_API int fmrx_stereo_combine(const float *stereo_final, const float *mono, s
 FMRX_API int fmrx_pcm16(const float *audio, size_t n, int16_t *out, int wrap);
 
 /* ------------------------------------------------------------------ */
+/* diagnostics                                                          */
+/* ------------------------------------------------------------------ */
+/* replaces estimatePSD  include/fourier.h, src/fourier.cpp:44-128 (with its DFT,
+ * :15-23): Bartlett average, in dB, of Hann-windowed nfft-point spectra of
+ * `samples`; the reference fixes nfft = NFFT = 512 (include/dy4.h:27).
+ * freq[nfft/2] (Hz), psd[nfft/2] (dB).  Requires n >= nfft, nfft even. */
+FMRX_API int fmrx_estimate_psd(float *freq, float *psd, const float *samples, size_t n, float Fs, int nfft);
+
+/* ------------------------------------------------------------------ */
 /* mode table and pipeline handle                                       */
 /* ------------------------------------------------------------------ */
 /* replaces struct PARAMS + the mode table  src/project.cpp:17-27, 424-427

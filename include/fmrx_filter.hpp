@@ -15,6 +15,7 @@
 // Define FMRX_FILTER_NO_GLOBAL to keep the names inside namespace fmrx only.
 #pragma once
 #include <cstdint>
+#include <fstream>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -149,6 +150,30 @@ inline void setVec(const std::vector<float> &vec1, std::vector<float> &vec2, int
     }
 }
 
+// include/fourier.h estimatePSD (src/fourier.cpp:44-128); NFFT = 512 (include/dy4.h:27)
+inline void estimatePSD(std::vector<float> &freq, std::vector<float> &psd_est, const std::vector<float> &samples, const float Fs)
+{
+    const int nfft = 512;
+    freq.assign(nfft / 2, 0.0f);
+    psd_est.assign(nfft / 2, 0.0f);
+    check(fmrx_estimate_psd(freq.data(), psd_est.data(), samples.data(), samples.size(), Fs, nfft));
+}
+
+// include/logfunc.h logVector (src/logfunc.cpp:23-43): the same gnuplot text format.  Host-side
+// file output, no device work; the reference hard-codes the directory "../data/Graphing/", here
+// `filename` is used as given (append ".dat" yourself or pass the reference's relative path).
+inline void logVector(const std::string &filename, const std::vector<float> &x, const std::vector<float> &y)
+{
+    std::ofstream fd(filename);
+    if (!fd) throw Error(FMRX_EINVAL, "logVector: cannot open " + filename);
+    fd << "#\tx_axis\ty_axis\n";
+    for (size_t i = 0; i < x.size(); i++) {
+        fd << "\t " << x[i] << "\t";
+        if (i < y.size()) fd << y[i];
+        fd << "\n";
+    }
+}
+
 // include/iofunc.h:36 -- the conversion of readStdinBlockData on bytes already
 // read (the stdin read itself stays with the caller).
 inline void convertBlockData(const std::vector<uint8_t> &raw, std::vector<float> &block_data)
@@ -167,6 +192,7 @@ using fmrx::convolveBlockFIR;
 using fmrx::convolveBlockResampleFIR;
 using fmrx::convolveFIR;
 using fmrx::downsample;
+using fmrx::estimatePSD;
 using fmrx::fmDemod;
 using fmrx::fmPLL;
 using fmrx::impulseResponseLPF;

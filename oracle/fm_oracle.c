@@ -501,6 +501,61 @@ size_t fmo_pipeline_intermediate(const fmo_pipeline *pl, int which, const float 
 }
 
 /* ------------------------------------------------------------------ */
+/* diagnostics: Bartlett PSD estimate                                     */
+/* ------------------------------------------------------------------ */
+
+/* src/fourier.cpp:44-128 with its DFT (:15-23) inlined.  float32 throughout
+ * except where a double literal forces double: the twiddle angle
+ * -2*PI*(k*m)/N is evaluated in double and rounded to float (it is the
+ * imaginary part of a std::complex<float>), std::exp(complex<float>) is
+ * (cosf, sinf) of that float (e^0 == 1), the bin power goes through
+ * std::pow(float, 2.0) in double.  Segments are averaged in dB. */
+int fmo_estimate_psd(float *freq, float *psd, const float *samples, size_t n, float Fs, int nfft)
+{
+    const int half = nfft / 2;
+    const float df = Fs / nfft;
+    /* LinearSpacedArray(freq, Fs/2, 0.0, df): N = (max-min)/step in float, i < N */
+    {
+        const float N = (Fs / 2 - 0.0f) / df;
+        for (int i = 0; i < half; i++)
+            freq[i] = (i < N) ? 0.0f + i * df : 0.0f;
+    }
+    float *hann = (float *)malloc(sizeof(float) * (size_t)nfft);
+    for (int i = 0; i < nfft; i++) {
+        const double sn = sin(i * FMO_PI / nfft);
+        hann[i] = (float)pow(sn, 2.0);
+    }
+    const int nseg = (int)floor((double)((float)n / (float)nfft));
+    float *acc = (float *)calloc((size_t)half, sizeof(float));
+    float *w = (float *)malloc(sizeof(float) * (size_t)nfft);
+    for (int sgm = 0; sgm < nseg; sgm++) {
+        for (int i = 0; i < nfft; i++)
+            w[i] = samples[(size_t)sgm * nfft + i] * hann[i];
+        for (int m = 0; m < half; m++) {
+            float re = 0.0f, im = 0.0f;
+            for (int k = 0; k < nfft; k++) {
+                const float ang = (float)(-2 * FMO_PI * (unsigned)(k * m) / (unsigned)nfft);
+                /* x * exp(i*ang): libstdc++ scales real and imaginary part by the real factor */
+                re += w[k] * cosf(ang);
+                im += w[k] * sinf(ang);
+            }
+            const float mag = hypotf(re, im);                 /* std::abs(complex<float>) */
+            float p = (float)((1 / (Fs * nfft / 2)) * pow((double)mag, 2.0));
+            p = 2 * p;
+            p = 10 * log10f(p);
+            acc[m] += p;    /* psd_est[k] += psd_list[...] in segment order */
+        }
+    }
+    /* the reference sums bin k over segments l = 0.. in order, then divides */
+    for (int m = 0; m < half; m++)
+        psd[m] = acc[m] / nseg;
+    free(w);
+    free(acc);
+    free(hann);
+    return nseg;
+}
+
+/* ------------------------------------------------------------------ */
 /* synthetic FM multiplex, closed form so that any window of  */
 /* the stream can be generated independently                              */
 /* ------------------------------------------------------------------ */

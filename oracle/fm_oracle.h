@@ -110,6 +110,13 @@ size_t fmo_pipeline_n_audio(const fmo_pipeline *pl, size_t n_bytes);
  * 4 allpass, 5 mono_filt, 6 stereo_final.  Returns length. */
 size_t fmo_pipeline_intermediate(const fmo_pipeline *pl, int which, const float **ptr);
 
+/* ---- diagnostics ----------------------------------- */
+/* src/fourier.cpp:44-128 estimatePSD: Bartlett average of Hann-windowed
+ * nfft-point DFTs (src/fourier.cpp:15-23), in dB; nfft = NFFT = 512
+ * (include/dy4.h:27).  freq[nfft/2], psd[nfft/2]; needs n >= nfft.
+ * Returns the number of segments averaged. */
+int fmo_estimate_psd(float *freq, float *psd, const float *samples, size_t n, float Fs, int nfft);
+
 /* ---- deterministic synthetic FM multiplex ---------------- */
 /* Fills iq[2*n_samples] with constant-envelope stereo-multiplex FM at rf_Fs,
  * starting at absolute sample index start (so consecutive calls continue the

@@ -22,6 +22,7 @@
 
 #include "dy4.h"
 #include "filter.h"
+#include "fourier.h"
 #include "iofunc.h"
 
 namespace {
@@ -151,6 +152,15 @@ void ref_pcm16(const float *a, size_t n, int16_t *out)
         else wav[k] = static_cast<short int>(a[k] * 16384);
     }
     std::memcpy(out, wav.data(), n * sizeof(short int));
+}
+
+int ref_estimate_psd(float *freq, float *psd, const float *samples, size_t n, float Fs)
+{
+    std::vector<float> f, p, v(samples, samples + n);
+    estimatePSD(f, p, v, Fs);
+    std::memcpy(freq, f.data(), f.size() * sizeof(float));
+    std::memcpy(psd, p.data(), p.size() * sizeof(float));
+    return (int)p.size();
 }
 
 // ---- block pipeline replaying project.cpp with the reference primitives ----

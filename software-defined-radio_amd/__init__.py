@@ -105,6 +105,7 @@ _sig("fmrx_fm_pll", [_f32p, _sz, _f32p, _f32p, _flt, _flt, _flt, _flt, _flt])
 _sig("fmrx_stereo_mix", [_f32p, _f32p, _sz, _f32p])
 _sig("fmrx_stereo_combine", [_f32p, _f32p, _sz, _f32p, _f32p])
 _sig("fmrx_pcm16", [_f32p, _sz, _i16p, _int])
+_sig("fmrx_estimate_psd", [_f32p, _f32p, _f32p, _sz, _flt, _int])
 _sig("fmrx_mode_params", [_int, _int, _int, _int, C.POINTER(Params)])
 _sig("fmrx_pipeline_create", [C.POINTER(_vp), C.POINTER(Params), _int, _sz, _int])
 _sig("fmrx_pipeline_destroy", [_vp])
@@ -266,6 +267,14 @@ def stereoCombine(stereo_final, mono):
     l, r = np.zeros(len(a), np.float32), np.zeros(len(a), np.float32)
     _check(lib.fmrx_stereo_combine(a, b, len(a), l, r))
     return l, r
+
+
+def estimatePSD(samples, Fs, nfft=512):
+    """fourier.h / fourier.cpp:44-128 -> (freq[nfft/2], psd_est[nfft/2] in dB); NFFT = 512 in the reference."""
+    x = _f32(samples)
+    freq, psd = np.zeros(nfft // 2, np.float32), np.zeros(nfft // 2, np.float32)
+    _check(lib.fmrx_estimate_psd(freq, psd, x, len(x), Fs, nfft))
+    return freq, psd
 
 
 def readBlockData(raw_u8) -> np.ndarray:

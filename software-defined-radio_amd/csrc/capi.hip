@@ -358,6 +358,26 @@ int fmrx_stereo_combine(const float *stereo_final, const float *mono, size_t n, 
     return d2h(right, s.d.p, n * sizeof(float));
 }
 
+// ---- diagnostics ---------------------------------------------------------------------------
+int fmrx_estimate_psd(float *freq, float *psd, const float *samples, size_t n, float Fs, int nfft)
+{
+    if (!freq || !psd || !samples) return fail(FMRX_EINVAL, "estimate_psd: null buffer");
+    if (nfft < 2 || nfft % 2 || nfft > 65536) return fail(FMRX_EINVAL, "estimate_psd: nfft must be even and in 2..65536");
+    if (n < static_cast<size_t>(nfft)) return fail(FMRX_EINVAL, "estimate_psd: %zu samples < nfft %d", n, nfft);
+    if (!(Fs > 0)) return fail(FMRX_EINVAL, "estimate_psd: Fs must be positive");
+    FMRX_TRY(require_device());
+    Scratch &s = scratch();
+    const size_t nseg = n / nfft, half = nfft / 2;
+    FMRX_TRY(s.a.ensure(n));
+    FMRX_TRY(s.b.ensure(nseg * half));
+    FMRX_TRY(s.c.ensure(half));
+    FMRX_TRY(s.d.ensure(half));
+    FMRX_TRY(h2d(s.a.p, samples, nseg * nfft * sizeof(float)));
+    FMRX_TRY(k_estimate_psd(s.a.p, n, Fs, nfft, s.b.p, s.c.p, s.d.p, nullptr));
+    FMRX_TRY(d2h(freq, s.c.p, half * sizeof(float)));
+    return d2h(psd, s.d.p, half * sizeof(float));
+}
+
 // ---- fused front end as a stage ----------------------------------------------------------
 struct fmrx_fe_plan {
     FePlan plan;

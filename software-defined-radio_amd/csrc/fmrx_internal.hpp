@@ -167,6 +167,10 @@ int k_upsample(const float *d_x, size_t n, float *d_xu, int up, hipStream_t s);
 int k_downsample(const float *d_in, size_t n_out, float *d_out, int ds, hipStream_t s);
 int k_fill_u8(uint8_t *d, size_t n, uint8_t v, hipStream_t s);
 
+// ---- diagnostics (kernels_psd.hip) ---------------------------------------------------
+// d_seg_db: (n/nfft)*(nfft/2) floats of scratch; d_freq, d_psd: nfft/2 floats
+int k_estimate_psd(const float *d_x, size_t n, float Fs, int nfft, float *d_seg_db, float *d_freq, float *d_psd, hipStream_t s);
+
 // ---- host-side coefficient design (coeff.cpp) --------------------------------
 void design_lpf(float Fs, float Fc, int taps, float *h);
 void design_bpf(float Fs, float Fb, float Fe, int taps, float *h);

@@ -161,6 +161,7 @@ class Oracle(_FirFamily):
         self._sig("fmo_pipeline_n_audio", C.c_size_t, [C.c_void_p, C.c_size_t])
         self._sig("fmo_pipeline_intermediate", C.c_size_t, [C.c_void_p, C.c_int, C.POINTER(C.POINTER(C.c_float))])
         self._sig("fmo_synth_fm_u8", None, [u8p, C.c_size_t, C.c_double, C.c_uint64, C.c_uint64])
+        self._sig("fmo_estimate_psd", C.c_int, [f32p, f32p, f32p, C.c_size_t, C.c_float, C.c_int])
 
     def u8_to_f32(self, raw):
         raw = np.ascontiguousarray(raw, np.uint8)
@@ -173,6 +174,12 @@ class Oracle(_FirFamily):
         out = np.zeros(len(a), np.int16)
         self.lib.fmo_pcm16(a, len(a), out, 1 if wrap else 0)
         return out
+
+    def estimate_psd(self, samples, Fs, nfft=512):
+        x = _f32(samples)
+        freq, psd = np.zeros(nfft // 2, np.float32), np.zeros(nfft // 2, np.float32)
+        self.lib.fmo_estimate_psd(freq, psd, x, len(x), Fs, nfft)
+        return freq, psd
 
     def mode_params(self, mode, rf_taps=101, base_audio_taps=101, stereo_taps=101) -> FmoParams:
         p = FmoParams()
@@ -230,6 +237,8 @@ class Ref(_FirFamily):
         self._sig("ref_read_block", None, [u8p, C.c_size_t, f32p])
         self._sig("ref_pcm16", None, [f32p, C.c_size_t, i16p])
         self._sig("ref_pipeline_create", C.c_void_p, [C.c_int] * 5)
+        if hasattr(self.lib, "ref_estimate_psd"):
+            self._sig("ref_estimate_psd", C.c_int, [f32p, f32p, f32p, C.c_size_t, C.c_float])
         self._sig("ref_pipeline_destroy", None, [C.c_void_p])
         self._sig("ref_pipeline_process", C.c_size_t, [C.c_void_p, u8p, C.c_size_t])
         self._sig("ref_pipeline_get", C.c_size_t, [C.c_void_p, C.c_int, C.POINTER(C.POINTER(C.c_float))])
@@ -249,6 +258,12 @@ class Ref(_FirFamily):
         out = np.zeros(len(a), np.int16)
         self.lib.ref_pcm16(a, len(a), out)
         return out
+
+    def estimate_psd(self, samples, Fs):
+        x = _f32(samples)
+        freq, psd = np.zeros(256, np.float32), np.zeros(256, np.float32)
+        self.lib.ref_estimate_psd(freq, psd, x, len(x), Fs)
+        return freq, psd
 
     def pipeline(self, mode=0, channels=1, rf_taps=101, base_audio_taps=101, stereo_taps=101):
         return RefPipeline(self, mode, channels, rf_taps, base_audio_taps, stereo_taps)

@@ -166,6 +166,18 @@ def main():
     g5["allpass_out"], g5["allpass_state"] = ap, aps
     save("edge.npz", **g5)
 
+    # ---- G7 diagnostics: estimatePSD (fourier.cpp:44-128) on the mode-0 audio and on a tone + noise ----
+    g7 = {}
+    pr = r.pipeline(0, 1, 101, 101, 101)
+    audio = np.concatenate([pr.process(inputs["mode0"][b * 102400:(b + 1) * 102400])["audio"] for b in range(2)])
+    g7["audio_in"] = audio
+    g7["audio_freq"], g7["audio_psd"] = r.estimate_psd(audio, 48e3)
+    t = np.arange(5000)
+    tone = (0.5 * np.cos(2 * np.pi * 3e3 * t / 48e3) + 0.1 * rng.standard_normal(5000)).astype(np.float32)   # 9 segments + a remainder
+    g7["tone_in"] = tone
+    g7["tone_freq"], g7["tone_psd"] = r.estimate_psd(tone, 48e3)
+    save("psd.npz", **g7)
+
     # ---- G6 process contract: the reference BINARY, u8 stdin -> s16 stdout ----
     # threadMonoOnly (rf_taps 151 / audio_taps 101).  Its EOF handling truncates
     # the output nondeterministically: keep the longest of a few

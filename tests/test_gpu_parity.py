@@ -483,6 +483,21 @@ def test_ragged_block_sizes(fmrx, oracle, channels):
         assert len(out["pcm16"]) == channels * len(ref["audio_l"])
 
 
+def test_estimate_psd(fmrx, oracle):
+    """estimatePSD on the GPU vs the golden vectors of the compiled reference: frequencies exact;
+    dB values within 2e-3 dB (the sine/cosine of the reference's float32 twiddle angles come from
+    v_sin/v_cos after a double reduction instead of glibc's sinf/cosf; deep nulls amplify that)."""
+    g = np.load(os.path.join(G, "psd.npz"))
+    for k in ("audio", "tone"):
+        f, p = fmrx.estimatePSD(g[f"{k}_in"], 48e3)
+        bits_equal(f, g[f"{k}_freq"])
+        d = np.abs(p - g[f"{k}_psd"])
+        print(k, "max dB diff", d.max())
+        assert d.max() <= 2e-3
+    with pytest.raises(fmrx.FmrxError):
+        fmrx.estimatePSD(np.zeros(100, np.float32), 48e3)
+
+
 def test_pipeline_rejects_bad_blocks(fmrx):
     pl = fmrx.Pipeline(0, 1)
     for n in (0, 102401, 102400 + 20, 2 * 102400):   # odd, not a multiple of decims, too large

@@ -170,3 +170,12 @@ def test_resampler_equals_up_fir_down(oracle):
     full = oracle.convolve_fir(oracle.upsample(x, U), h)[: n * U]
     ref = oracle.downsample(full, D).astype(np.float64) * (1 + U)
     np.testing.assert_allclose(y, ref[: len(y)], rtol=2e-5, atol=2e-6)
+
+
+def test_psd_golden(oracle):
+    g = load("psd.npz")
+    for k in ("audio", "tone"):
+        f, p = oracle.estimate_psd(g[f"{k}_in"], 48e3)
+        bits_equal(f, g[f"{k}_freq"]); bits_equal(p, g[f"{k}_psd"])
+    assert int(np.argmax(g["tone_psd"])) == 32          # 3 kHz at 48 kHz / 512 per bin
+    assert np.all(np.diff(g["tone_freq"]) == np.float32(93.75))
