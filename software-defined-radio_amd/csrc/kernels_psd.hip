@@ -10,8 +10,8 @@
 // and add); |X|^2 scaling, x2 for the negative frequencies, 10 log10; then the
 // segments are averaged in dB, in segment order.  The twiddle angle is the
 // reference's float32 value fl(-2*PI*(k*m)/N) (up to 3.2e3 rad: its rounding IS
-// part of the reference's result); its sine and cosine come from one
-// double-precision reduction + v_sin_f32/v_cos_f32 (|error| ~ 1e-6).
+// part of the reference's result); sine and cosine of it come from the device
+// math library (this is a diagnostic, accuracy over speed).
 #include "fmrx_internal.hpp"
 
 #pragma clang fp contract(off)
@@ -27,16 +27,15 @@ __global__ void psd_segments_kernel(const float *__restrict__ x, int nfft, int n
     if (gid >= static_cast<long>(nseg) * half) return;
     const int sg = static_cast<int>(gid / half), m = static_cast<int>(gid % half);
     const float *xs = x + static_cast<long>(sg) * nfft;
-    const double PI = 3.14159265358979323846, inv2pi = 0.15915494309189533577;
+    const double PI = 3.14159265358979323846;
     float re = 0.0f, im = 0.0f;
     for (int k = 0; k < nfft; k++) {
         const double sn = sin(k * PI / nfft);
         const float hann = static_cast<float>(sn * sn);                 // std::pow(std::sin(i*PI/N), 2.0)
         const float w = xs[k] * hann;
         const float ang = static_cast<float>(-2 * PI * static_cast<unsigned>(k * m) / static_cast<unsigned>(nfft));
-        const double rev = static_cast<double>(ang) * inv2pi;
-        const float fr = static_cast<float>(rev - rint(rev));
-        const float c = __builtin_amdgcn_cosf(fr), s = __builtin_amdgcn_sinf(fr);
+        float s, c;
+        sincosf(ang, &s, &c);   // library accuracy: the spectrum's deep nulls amplify twiddle errors
         const float pr = w * c, pi = w * s;
         re = re + pr;
         im = im + pi;
