@@ -485,17 +485,19 @@ def test_ragged_block_sizes(fmrx, oracle, channels):
 
 def test_estimate_psd(fmrx, oracle):
     """estimatePSD on the GPU vs the golden vectors of the compiled reference: frequencies exact;
-    dB values within 2e-3 dB for every bin within 100 dB of the peak (device sinf/cosf differ from
-    glibc's by ulps; bins 140 dB down, where 512 terms cancel, amplify that: 0.2 dB allowed there)."""
+    dB values within 1e-3 dB for bins in the top 60 dB (device sinf/cosf differ from glibc's by ulps;
+    weaker bins, where 512 terms cancel, amplify that)."""
     g = np.load(os.path.join(G, "psd.npz"))
     for k in ("audio", "tone"):
         f, p = fmrx.estimatePSD(g[f"{k}_in"], 48e3)
         bits_equal(f, g[f"{k}_freq"])
         want = g[f"{k}_psd"]
         d = np.abs(p - want)
-        strong = want >= want.max() - 100.0          # bins within 100 dB of the peak
-        print(k, "max dB diff", d.max(), "within 100 dB of the peak", d[strong].max())
-        assert d[strong].max() <= 2e-3 and d.max() <= 0.2   # nulls 140 dB down amplify 1-ulp sincos differences
+        top60, top100 = want >= want.max() - 60.0, want >= want.max() - 100.0
+        print(k, "max dB diff", d.max(), "top 100 dB", d[top100].max(), "top 60 dB", d[top60].max())
+        # the further a bin is below the peak, the more of its 512 terms cancel and the more a 1-ulp
+        # sincos difference shows: 1e-3 dB in the top 60 dB, 1e-2 dB in the top 100 dB, 0.2 dB in the nulls
+        assert d[top60].max() <= 1e-3 and d[top100].max() <= 1e-2 and d.max() <= 0.2
     with pytest.raises(fmrx.FmrxError):
         fmrx.estimatePSD(np.zeros(100, np.float32), 48e3)
 
