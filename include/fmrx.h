@@ -264,8 +264,9 @@ FMRX_API int fmrx_fe_plan_destroy(fmrx_fe_plan *plan);
 /* 1 when a specialised (register-window, packed-FMA) kernel exists for the
  * plan's (taps, decim); 0 when it will run the generic kernel */
 FMRX_API int fmrx_fe_plan_is_specialised(const fmrx_fe_plan *plan);
-/* bytes of history the kernel reads in front of a block: 2*(taps-1) rounded up
- * to a multiple of 16; the LAST 2*(taps-1) bytes are the previous samples */
+/* bytes of history kept in front of a block: 2*(taps-1) rounded up to a multiple
+ * of 16, plus 16*decim (so the fused kernel can recompute the previous block's
+ * last IF samples); the LAST 2*(taps-1) bytes are the reference's I_state/Q_state */
 FMRX_API size_t fmrx_fe_plan_history_bytes(const fmrx_fe_plan *plan);
 /* d_iq: DEVICE, 16-byte aligned, 2*n_samples bytes.  d_hist: DEVICE,
  * history_bytes bytes, or NULL for silence.  d_if: DEVICE, interleaved float

@@ -11,11 +11,12 @@
 // are kernels on one HIP stream, so the hand-off is stream order.
 //
 // Device layout of one block (n = complex input samples, n_if = n/rf_decim):
-//   in      u8   [hist_bytes | 2n]            raw I/Q, FE history in front
-//   ifb     f32  [2 n_if]                     interleaved IF I,Q
+//   in      u8   [2n]                         raw I/Q (host-buffer entry point only; process_dev reads the caller's)
+//   fe_hist u8   [hist_bytes] x2              the stream's last bytes (= I_state/Q_state), ping-pong
+//   ifb     f32  [2 n_if]                     interleaved IF I,Q -- only with set_keep_intermediates / generic path
 //   demod   f32  [Hd | n_if]                  discriminator output, history in front
-//   mono    f32  [n_audio]
-//   stereo: carrier, bpf [n_if]; pll [n_if+1]; mixer [Ha | n_if]; final, L, R [n_audio]
+//   mono    f32  [n_audio]                    (mono modes 0/1 write straight into the caller's buffers)
+//   stereo: carrier, bpf [n_if]; pll [n_if+1]; mixer [Hm | n_if]; final, L, R [n_audio]
 // The all-pass delay of the stereo path (project.cpp:194, filter.cpp:14-29) is
 // not a kernel: the mono audio FIR simply reads demod `delay` samples earlier.
 #include "fmrx_internal.hpp"
