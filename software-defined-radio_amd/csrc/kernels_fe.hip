@@ -484,6 +484,10 @@ int launch_fused(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const 
     long per_cu = (160 * 1024) / lds_wg;
     if (per_cu > 4) per_cu = 4;
     if (per_cu < 1) per_cu = 1;
+    if (const char *e = std::getenv("FMRX_FE_WGS_PER_CU")) {   // tuning knob (tools/fe_occ_ab.py)
+        const long v = std::atol(e);
+        if (v >= 1 && v < per_cu) per_cu = v;
+    }
     const long want = (n_wtiles + 3) / 4;
     const unsigned grid = static_cast<unsigned>(want < 256 * per_cu ? want : 256 * per_cu);
     hipLaunchKernelGGL((fe_demod_kernel<T, D, R>), dim3(grid), dim3(256), static_cast<size_t>(lds_wg), stream, d_iq, d_hist,
