@@ -133,6 +133,33 @@ def test_resampler_stage(fmrx, oracle, U, D, n):
     bits_equal(y2, yo); bits_equal(st3, sto)
 
 
+def test_maximum_tap_count_and_non_finite_samples(fmrx, oracle):
+    """The reference's tap count is an unsigned short: 65 535 taps is the maximum.  NaN / Inf samples
+    must poison exactly the outputs whose window contains them, as in the reference."""
+    rng = np.random.default_rng(8)
+    T, D, n = 65535, 7, 70000
+    h = (rng.standard_normal(T) / T).astype(np.float32)
+    x = rng.standard_normal(n).astype(np.float32)
+    st = rng.standard_normal(T - 1).astype(np.float32)
+    y, s2 = fmrx.convolveBlockFastFIR(x, h, st, D)
+    yo, so = oracle.convolve_block_fast_fir(x, h, st, D)
+    bits_equal(y, yo); bits_equal(s2, so)
+    with pytest.raises(fmrx.FmrxError):
+        fmrx.convolveBlockFastFIR(x, np.zeros(65536, np.float32), np.zeros(65535, np.float32), D)   # > unsigned short
+    x2 = rng.standard_normal(4000).astype(np.float32)
+    x2[1234], x2[2500] = np.nan, np.inf
+    h2 = fmrx.impulseResponseLPF(240e3, 16e3, 101)
+    y, _ = fmrx.convolveBlockFastFIR(x2, h2, np.zeros(100, np.float32), 5)
+    yo, _ = oracle.convolve_block_fast_fir(x2, h2, np.zeros(100, np.float32), 5)
+    np.testing.assert_array_equal(np.isnan(y), np.isnan(yo))
+    ok = ~np.isnan(yo)
+    bits_equal(y[ok], yo[ok])
+    assert np.isnan(yo).sum() >= 20
+    # zero-length inputs are accepted by the element-wise stages
+    assert len(fmrx.readBlockData(np.zeros(0, np.uint8))) == 0
+    assert len(fmrx.pcm16(np.zeros(0, np.float32))) == 0
+
+
 def test_demod_allpass_mix_updown(fmrx, oracle, sig):
     g = np.load(os.path.join(G, "edge.npz"))
     d, pi, pq = fmrx.fmDemod(g["demod_I"], g["demod_Q"], 0.25, -0.5)   # includes den==0 samples
