@@ -22,7 +22,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfmrx.so")
+LIB_PATH = os.environ.get("FMRX_LIB") or os.path.join(_HERE, "lib", "libfmrx.so")   # FMRX_LIB: A/B a development build
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "fmrx.h")
 
 OK, EINVAL, ENODEV, EHIP, ENOMEM = 0, 1, 2, 3, 4

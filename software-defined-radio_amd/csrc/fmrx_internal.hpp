@@ -84,8 +84,11 @@ int fe_hist_bytes(int taps, int decim);
 // written; d_if (interleaved I,Q) and d_prev_out (float2 = IF[n/decim-1]) are
 // optional; d_prev_override (float2) replaces the recomputed IF[-1] when given.
 bool fe_fused_available(const FePlan &pl, const uint8_t *d_iq, size_t n_samples);
+// d_hist_next (optional, hist_bytes bytes, requires 2*n_samples >= hist_bytes): the kernel also leaves
+// the block's last bytes there for the next block.
 int fe_demod_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist,
-                    const float *d_prev_override, float *d_demod, float *d_if, float *d_prev_out, hipStream_t stream);
+                    const float *d_prev_override, float *d_demod, float *d_if, float *d_prev_out,
+                    uint8_t *d_hist_next, hipStream_t stream);
 
 // ---- audio fast path (kernels_audio.hip) --------------------------------------
 struct AudioPlan {
@@ -98,9 +101,12 @@ int audio_plan_init(AudioPlan &pl, const float *h, int taps, int decim);
 // y[k] = sum_n h[n] * x[decim*k - n - delay]; x points at the block start and
 // x[-(taps-1+delay+3) .. -1] must be readable history (the specialised kernel
 // loads 16-byte chunks).
-// Optionally also writes s16 PCM (d_pcm != nullptr).
-int audio_fir_launch(const AudioPlan &pl, const float *d_x, size_t n_in, int delay, float *d_y, int16_t *d_pcm, int wrap,
-                     hipStream_t stream, bool force_generic);
+// Optionally also writes s16 PCM (d_pcm != nullptr).  d_hist_end (optional, specialised kernel only):
+// one past the last sample of the previous block; when given, samples before d_x[0] are read from
+// d_hist_end[-1], d_hist_end[-2], ... instead of d_x[-1], d_x[-2], ...
+bool audio_fast_available(const AudioPlan &pl, const float *d_x);
+int audio_fir_launch(const AudioPlan &pl, const float *d_x, const float *d_hist_end, size_t n_in, int delay, float *d_y,
+                     int16_t *d_pcm, int wrap, hipStream_t stream, bool force_generic);
 
 // ---- rational resampler (kernels_resample.hip) ------------------------------------
 struct ResamplePlan {

@@ -103,7 +103,8 @@ __device__ __forceinline__ void au_step(const uint8_t *tb, const float *__restri
 
 // loads of one tile: NIT independent 16-byte loads per thread, all in flight together
 template <int T, int D, int R, int NT, int NIT>
-__device__ __forceinline__ void au_fetch(const float *__restrict__ xh, long n_in, int delay, long tile, int t, f4 (&v)[NIT])
+__device__ __forceinline__ void au_fetch(const float *__restrict__ xh, const float *__restrict__ hist_end, long n_in, int delay,
+                                         long tile, int t, f4 (&v)[NIT])
 {
     using C = AuCfg<T, D, R, NT>;
     constexpr int NCH4 = (C::WL + 3) / 4 + 1;
@@ -115,16 +116,24 @@ __device__ __forceinline__ void au_fetch(const float *__restrict__ xh, long n_in
         const int half = cc >= NCH4 ? 1 : 0;
         const long g0 = gal + static_cast<long>(half) * (D * C::HALF) + 4L * (cc - half * NCH4);
         v[it] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
-        if (cc < 2 * NCH4 && g0 < n_in) v[it] = *reinterpret_cast<const f4 *>(xh + g0);
+        if (cc < 2 * NCH4 && g0 < n_in) {
+            if (g0 >= 0 || !hist_end) {
+                v[it] = *reinterpret_cast<const f4 *>(xh + g0);   // chunks start at multiples of 4: never straddle 0
+            } else {
+                // history lives at the tail of the previous block's buffer (no alignment guarantee)
+                v[it] = (f4){hist_end[g0], hist_end[g0 + 1], hist_end[g0 + 2], hist_end[g0 + 3]};
+            }
+        }
     }
 }
 
 // Persistent workgroups: the next tile's samples are loaded into registers while
 // this tile's FMAs run, so HBM latency is not in front of the barrier.
 template <int T, int D, int R, int NT>
-__global__ __launch_bounds__(NT) void audio_fir_kernel(const float *__restrict__ xh, long n_in, int delay,
-                                                        const float *__restrict__ table, float *__restrict__ y,
-                                                        int16_t *__restrict__ pcm, int wrap, long n_out, long n_tiles)
+__global__ __launch_bounds__(NT) void audio_fir_kernel(const float *__restrict__ xh, const float *__restrict__ hist_end,
+                                                        long n_in, int delay, const float *__restrict__ table,
+                                                        float *__restrict__ y, int16_t *__restrict__ pcm, int wrap,
+                                                        long n_out, long n_tiles)
 {
     using C = AuCfg<T, D, R, NT>;
     extern __shared__ f4 lds4[];
@@ -136,41 +145,45 @@ __global__ __launch_bounds__(NT) void audio_fir_kernel(const float *__restrict__
 
     f4 v[NIT];
     long tile = blockIdx.x;
-    if (tile < n_tiles) au_fetch<T, D, R, NT, NIT>(xh, n_in, delay, tile, t, v);
+    if (tile < n_tiles) au_fetch<T, D, R, NT, NIT>(xh, hist_end, n_in, delay, tile, t, v);
     for (; tile < n_tiles; tile += gridDim.x) {
         const long a0 = tile * (2 * C::HALF);            // first output of the low half
         const long gbase = D * a0 - (T - 1) - delay;
         const long gal = gbase & ~3L;
         const int off = static_cast<int>(gbase - gal);   // where the window starts inside its first 16-byte chunk
         // ---- scatter the prefetched samples into (lo,hi) pair slots, stream order + pads ----
+        // interior tiles (every chunk inside [0, n_in) or in the history, wave-uniform test) skip the
+        // per-element range checks on values; chunks wholly inside the window skip the slot checks too
+        const bool interior = gal + 4L * NCH4 + static_cast<long>(D) * C::HALF <= n_in;
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
             const int cc = t + it * NT;
             if (cc < 2 * NCH4) {
                 const int half = cc >= NCH4 ? 1 : 0;
                 const int c = cc - half * NCH4;
-                const long g0 = gal + static_cast<long>(half) * (D * C::HALF) + 4L * c;
                 const int j0 = 4 * c - off;                  // window index of v.x; >= -3
                 const int jq = ((j0 + C::PADP) * (65536 / C::PADP + 1)) >> 16;   // (j0 + PADP) / PADP
-                int rem = j0 + C::PADP - jq * C::PADP;       // j0 mod PADP
-                int addr = (j0 + jq - 1) * 8 + half * 4;     // slot of j0: (j0 + j0/PADP)*8
+                const int rem = j0 + C::PADP - jq * C::PADP;                     // j0 mod PADP
+                const int addr = (j0 + jq - 1) * 8 + half * 4;                   // slot of j0: (j0 + j0/PADP)*8
+                if (interior && j0 >= 0 && j0 + 3 < C::WL) {
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const float val = (g0 + e < n_in) ? v[it][e] : 0.0f;
-                    const bool ok = static_cast<unsigned>(j0 + e) < static_cast<unsigned>(C::WL);
-                    *reinterpret_cast<float *>(ldsb + (ok ? addr : DUMP)) = val;
-                    addr += 8;
-                    rem++;
-                    if (rem == C::PADP) {                    // next thread-stride: skip its pad slot
-                        rem = 0;
-                        addr += 8;
+                    for (int e = 0; e < 4; e++)              // +8 once the chunk has crossed into the next thread-stride (pad slot)
+                        *reinterpret_cast<float *>(ldsb + addr + 8 * e + (rem + e >= C::PADP ? 8 : 0)) = v[it][e];
+                } else {
+                    const long g0 = gal + static_cast<long>(half) * (D * C::HALF) + 4L * c;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float val = (g0 + e < n_in) ? v[it][e] : 0.0f;
+                        const bool ok = static_cast<unsigned>(j0 + e) < static_cast<unsigned>(C::WL);
+                        const int a = addr + 8 * e + (rem + e >= C::PADP ? 8 : 0);
+                        *reinterpret_cast<float *>(ldsb + (ok ? a : DUMP)) = val;
                     }
                 }
             }
         }
         __syncthreads();
         const long next = tile + gridDim.x;
-        if (next < n_tiles) au_fetch<T, D, R, NT, NIT>(xh, n_in, delay, next, t, v);
+        if (next < n_tiles) au_fetch<T, D, R, NT, NIT>(xh, hist_end, n_in, delay, next, t, v);
 
         f2 acc[R];
 #pragma unroll
@@ -201,8 +214,8 @@ __global__ __launch_bounds__(NT) void audio_fir_kernel(const float *__restrict__
 }
 
 template <int T, int D>
-int launch_fast(const AudioPlan &pl, const float *d_x, size_t n_in, int delay, float *d_y, int16_t *d_pcm, int wrap,
-                hipStream_t stream)
+int launch_fast(const AudioPlan &pl, const float *d_x, const float *d_hist_end, size_t n_in, int delay, float *d_y,
+                int16_t *d_pcm, int wrap, hipStream_t stream)
 {
     constexpr int R = 4, NT = 256;
     using C = AuCfg<T, D, R, NT>;
@@ -211,7 +224,7 @@ int launch_fast(const AudioPlan &pl, const float *d_x, size_t n_in, int delay, f
     long per_cu = (160 * 1024) / C::LDS_BYTES;
     if (per_cu > 4) per_cu = 4;
     const unsigned grid = static_cast<unsigned>(n_tiles < 256 * per_cu ? n_tiles : 256 * per_cu);
-    hipLaunchKernelGGL((audio_fir_kernel<T, D, R, NT>), dim3(grid), dim3(NT), C::LDS_BYTES, stream, d_x,
+    hipLaunchKernelGGL((audio_fir_kernel<T, D, R, NT>), dim3(grid), dim3(NT), C::LDS_BYTES, stream, d_x, d_hist_end,
                        static_cast<long>(n_in), delay, pl.table.p, d_y, d_pcm, wrap, n_out, n_tiles);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FMRX_EHIP, "launch audio_fir_kernel<%d,%d>: %s", T, D, hipGetErrorString(e));
@@ -258,17 +271,24 @@ int audio_plan_init(AudioPlan &pl, const float *h, int taps, int decim)
     return FMRX_OK;
 }
 
-int audio_fir_launch(const AudioPlan &pl, const float *d_x, size_t n_in, int delay, float *d_y, int16_t *d_pcm, int wrap,
-                     hipStream_t stream, bool force_generic)
+// the specialised kernel reads 16-byte chunks relative to d_x: d_x must be 16-byte aligned
+bool audio_fast_available(const AudioPlan &pl, const float *d_x)
+{
+    return pl.fast && reinterpret_cast<uintptr_t>(d_x) % 16 == 0;
+}
+
+int audio_fir_launch(const AudioPlan &pl, const float *d_x, const float *d_hist_end, size_t n_in, int delay, float *d_y,
+                     int16_t *d_pcm, int wrap, hipStream_t stream, bool force_generic)
 {
     if (n_in / pl.decim == 0) return FMRX_OK;
-    // the specialised kernel reads 16-byte chunks relative to d_x: d_x must be 16-byte aligned
-    if (pl.fast && !force_generic && reinterpret_cast<uintptr_t>(d_x) % 16 == 0) {
+    if (audio_fast_available(pl, d_x) && !force_generic) {
 #define X(T_, D_) \
-    if (pl.taps == T_ && pl.decim == D_) return launch_fast<T_, D_>(pl, d_x, n_in, delay, d_y, d_pcm, wrap, stream);
+    if (pl.taps == T_ && pl.decim == D_) \
+        return launch_fast<T_, D_>(pl, d_x, d_hist_end, n_in, delay, d_y, d_pcm, wrap, stream);
         FMRX_AUDIO_CASES(X)
 #undef X
     }
+    if (d_hist_end) return fail(FMRX_EINVAL, "audio_fir_launch: split history needs the specialised kernel");
     FMRX_TRY(k_fir_generic(d_x - delay, n_in / pl.decim, pl.h.p, pl.taps, pl.decim, d_y, stream));
     if (d_pcm) FMRX_TRY(k_pcm16(d_y, n_in / pl.decim, d_pcm, wrap, stream));
     return FMRX_OK;

@@ -373,7 +373,7 @@ template <int T, int D, int R>
 __global__ __launch_bounds__(256, (FeWaveCfg<T, D, R>::MINW)) void fe_demod_kernel(
     const uint8_t *__restrict__ x, const uint8_t *__restrict__ hist, long n_bytes, const float *__restrict__ table,
     const float2 *__restrict__ prev_override, float *__restrict__ demod, f2 *__restrict__ y_if,
-    float2 *__restrict__ prev_out, long n_out, int n_wtiles)
+    float2 *__restrict__ prev_out, long n_out, int n_wtiles, uint8_t *__restrict__ hist_next, int hist_bytes)
 {
     using W = FeWaveCfg<T, D, R>;
     using C = typename W::C;
@@ -385,6 +385,11 @@ __global__ __launch_bounds__(256, (FeWaveCfg<T, D, R>::MINW)) void fe_demod_kern
     // tile index: the same in every lane; tell the compiler (scalar address math, uniform branches)
     int w = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * 4 + wave);
     const uint32_t flip = 0x80808080u;                         // u ^ 0x80 = (u - 128) as int8
+
+    // the stream's last bytes become the next block's history (I_state/Q_state of the reference,
+    // src/filter.cpp:182-187): one wave copies them; host guarantees n_bytes >= hist_bytes
+    if (hist_next && blockIdx.x == 0 && wave == 0)
+        for (int i = lane; i < hist_bytes; i += 64) hist_next[i] = x[n_bytes - hist_bytes + i];
 
     if (w < n_wtiles) fe_dma_tile<T, D, R>(x, hist, n_bytes, w, wl, lane);
     bool two_stores = false;   // wave-uniform: the previous iteration issued exactly its two demod stores after the DMA
@@ -474,7 +479,7 @@ __global__ __launch_bounds__(256, (FeWaveCfg<T, D, R>::MINW)) void fe_demod_kern
 
 template <int T, int D, int R>
 int launch_fused(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist, const float *d_prev_override,
-                 float *d_demod, float *d_if, float *d_prev_out, hipStream_t stream)
+                 float *d_demod, float *d_if, float *d_prev_out, uint8_t *d_hist_next, hipStream_t stream)
 {
     using W = FeWaveCfg<T, D, R>;
     if (d_hist) d_hist += pl.hist_bytes - W::HBX;   // the kernel reads the last HBX bytes of the history
@@ -493,7 +498,7 @@ int launch_fused(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const 
     hipLaunchKernelGGL((fe_demod_kernel<T, D, R>), dim3(grid), dim3(256), static_cast<size_t>(lds_wg), stream, d_iq, d_hist,
                        static_cast<long>(2 * n_samples), pl.table.p, reinterpret_cast<const float2 *>(d_prev_override),
                        d_demod, reinterpret_cast<f2 *>(d_if), reinterpret_cast<float2 *>(d_prev_out), n_out,
-                       static_cast<int>(n_wtiles));
+                       static_cast<int>(n_wtiles), d_hist_next, pl.hist_bytes);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FMRX_EHIP, "launch fe_demod_kernel<%d,%d>: %s", T, D, hipGetErrorString(e));
     return FMRX_OK;
@@ -610,12 +615,14 @@ bool fe_fused_available(const FePlan &pl, const uint8_t *d_iq, size_t n_samples)
 }
 
 int fe_demod_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist,
-                    const float *d_prev_override, float *d_demod, float *d_if, float *d_prev_out, hipStream_t stream)
+                    const float *d_prev_override, float *d_demod, float *d_if, float *d_prev_out,
+                    uint8_t *d_hist_next, hipStream_t stream)
 {
     if (n_samples / pl.decim == 0) return FMRX_OK;
 #define X(T_, D_) \
     if (pl.taps == T_ && pl.decim == D_) \
-        return launch_fused<T_, D_, 8>(pl, d_iq, n_samples, d_hist, d_prev_override, d_demod, d_if, d_prev_out, stream);
+        return launch_fused<T_, D_, 8>(pl, d_iq, n_samples, d_hist, d_prev_override, d_demod, d_if, d_prev_out, \
+                                       d_hist_next, stream);
     FMRX_FE_CASES(X)
 #undef X
     return fail(FMRX_EINVAL, "fe_demod_launch: no specialised kernel for taps=%d decim=%d", pl.taps, pl.decim);

@@ -14,7 +14,7 @@
 //   in      u8   [2n]                         raw I/Q (host-buffer entry point only; process_dev reads the caller's)
 //   fe_hist u8   [hist_bytes] x2              the stream's last bytes (= I_state/Q_state), ping-pong
 //   ifb     f32  [2 n_if]                     interleaved IF I,Q -- only with set_keep_intermediates / generic path
-//   demod   f32  [Hd | n_if]                  discriminator output, history in front
+//   demod   f32  [Hd | n_if] x2               discriminator output; the previous block's tail is the history
 //   mono    f32  [n_audio]                    (mono modes 0/1 write straight into the caller's buffers)
 //   stereo: carrier, bpf [n_if]; pll [n_if+1]; mixer [Hm | n_if]; final, L, R [n_audio]
 // The all-pass delay of the stereo path (project.cpp:194, filter.cpp:14-29) is
@@ -52,7 +52,14 @@ struct fmrx_pipeline {
     int fe_cur = 0;
     DevBuf<float> prev_iq[2];
     int prev_cur = 0;
-    DevBuf<float> ifb, demod, mono, tmp_hist;
+    DevBuf<float> ifb, mono, tmp_hist;
+    // discriminator output, two buffers [Hd | n_if] used alternately: the history of a block is the
+    // tail of the previous block's buffer, so nothing has to be copied between blocks unless a kernel
+    // needs it contiguous in front of its input (materialise_history)
+    DevBuf<float> demod_buf[2];
+    int demod_last = 0;          // buffer that holds the last processed block
+    size_t demod_n_last = 0;     // its length; its history front is valid iff demod_front[demod_last]
+    bool demod_front[2] = {true, true};
     DevBuf<float> carrier, bpf, pll, pll_state, pll_scratch, mixer, st_final, left, right;
     DevBuf<float> out_f32;
     DevBuf<int16_t> out_pcm;
@@ -78,22 +85,6 @@ __global__ void hist_update_kernel(const uint8_t *__restrict__ old_hist, const u
     new_hist[i] = src >= 0 ? x[src] : old_hist[hb + src];
 }
 
-// One launch for the per-block state carry of the mono path: the front end's byte
-// history (as hist_update_kernel) and the audio stage's float history (the last
-// `keep` demod samples move in front of the buffer; requires n_block >= keep so
-// source and destination do not overlap).
-__global__ void state_carry_kernel(const uint8_t *__restrict__ old_hist, const uint8_t *__restrict__ x, long n_bytes,
-                                   int hb, uint8_t *__restrict__ new_hist, float *__restrict__ buf, int keep,
-                                   long n_block)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < hb) {
-        const long src = static_cast<long>(i) + n_bytes - hb;
-        new_hist[i] = src >= 0 ? x[src] : old_hist[hb + src];
-    }
-    if (i < keep) buf[i] = buf[n_block + i];
-}
-
 int n_if_of(const fmrx_pipeline *pl, size_t n_bytes) { return static_cast<int>((n_bytes / 2) / pl->p.rf_decim); }
 
 size_t n_audio_of(const fmrx_pipeline *pl, size_t n_bytes)
@@ -116,7 +107,7 @@ int carry_history(fmrx_pipeline *pl, float *buf, int keep, size_t n_block, hipSt
 int audio_stage(fmrx_pipeline *pl, const float *d_x, size_t n_in, int delay, float *d_y, hipStream_t s)
 {
     if (pl->resample) return resample_launch(pl->rs, d_x, n_in, delay, d_y, s, pl->force_generic);
-    return audio_fir_launch(pl->audio, d_x, n_in, delay, d_y, nullptr, 0, s, pl->force_generic);
+    return audio_fir_launch(pl->audio, d_x, nullptr, n_in, delay, d_y, nullptr, 0, s, pl->force_generic);
 }
 
 
@@ -127,7 +118,10 @@ int reset_state(fmrx_pipeline *pl)
         FMRX_TRY(k_fill_u8(pl->fe_hist[i].p, pl->fe.hist_bytes, 128, s));
         FMRX_HIP(hipMemsetAsync(pl->prev_iq[i].p, 0, 2 * sizeof(float), s));
     }
-    FMRX_HIP(hipMemsetAsync(pl->demod.p, 0, pl->Hd * sizeof(float), s));
+    for (int i = 0; i < 2; i++) FMRX_HIP(hipMemsetAsync(pl->demod_buf[i].p, 0, pl->Hd * sizeof(float), s));
+    pl->demod_last = 0;
+    pl->demod_n_last = 0;
+    pl->demod_front[0] = pl->demod_front[1] = true;
     if (pl->channels == 2) {
         FMRX_HIP(hipMemsetAsync(pl->mixer.p, 0, pl->Hm * sizeof(float), s));
         const float init[6] = {0.0f, 0.0f, 1.0f, 0.0f, 1.0f, 0.0f};  // src/project.cpp:458
@@ -220,7 +214,7 @@ int fmrx_pipeline_create(fmrx_pipeline **out, const fmrx_params *p, int channels
             FMRX_TRY(pl->prev_iq[i].alloc(2));
         }
         FMRX_TRY(pl->ifb.alloc(2 * n_if + 16));
-        FMRX_TRY(pl->demod.alloc(pl->Hd + n_if + 16));
+        for (int i = 0; i < 2; i++) FMRX_TRY(pl->demod_buf[i].alloc(pl->Hd + n_if + 16));
         FMRX_TRY(pl->tmp_hist.alloc(pl->Hd + pl->Hm + 16));
         FMRX_TRY(pl->mono.alloc(n_au));
         if (channels == 2) {
@@ -326,19 +320,34 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
     const size_t n_au = n_audio_of(pl, n_bytes);
     pl->last_n_if = n_if;
     pl->last_n_audio = n_au;
-    float *demod = pl->demod.p + pl->Hd;
+    // this block's discriminator output goes to the buffer the previous block did not use
+    const int last = pl->demod_last, cur = last ^ 1;
+    float *dbuf = pl->demod_buf[cur].p;
+    float *demod = dbuf + pl->Hd;
+    const float *hist_end = pl->demod_buf[last].p + pl->Hd + pl->demod_n_last;   // one past the previous block's last sample
+    pl->demod_front[cur] = false;
+    auto materialise_history = [&]() -> int {   // for kernels that index history at negative offsets of their input
+        FMRX_HIP(hipMemcpyAsync(dbuf, hist_end - pl->Hd, pl->Hd * sizeof(float), hipMemcpyDeviceToDevice, s));
+        pl->demod_front[cur] = true;
+        return FMRX_OK;
+    };
 
     hipEvent_t *ev = pl->ev[pl->calls % fmrx_pipeline::kRing];
     if (pl->profiling) FMRX_HIP(hipEventRecord(ev[0], s));
 
     // ---- RF_FrontEnd: project.cpp:82-128 (u8 -> IF I/Q -> discriminator) ----
     const uint8_t *hist = pl->fe_hist[pl->fe_cur].p;
+    uint8_t *hist_next = pl->fe_hist[pl->fe_cur ^ 1].p;
+    const int hb = pl->fe.hist_bytes;
     const float *prev = pl->prev_iq[pl->prev_cur].p;
     float *prev_next = pl->prev_iq[pl->prev_cur ^ 1].p;
+    bool hist_done = false;
     if (!pl->force_generic && fe_fused_available(pl->fe, d_iq, n)) {
-        // one kernel; the IF stream is written only when somebody asked to look at it
+        // one kernel; the IF stream is written only when somebody asked to look at it, and the kernel
+        // also leaves the stream's last bytes (I_state/Q_state, filter.cpp:182-187) for the next block
+        hist_done = n_bytes >= static_cast<size_t>(hb);
         FMRX_TRY(fe_demod_launch(pl->fe, d_iq, n, hist, pl->prev_override ? prev : nullptr, demod,
-                                 pl->keep_if ? pl->ifb.p : nullptr, prev_next, s));
+                                 pl->keep_if ? pl->ifb.p : nullptr, prev_next, hist_done ? hist_next : nullptr, s));
         pl->if_valid = pl->keep_if;
     } else {
         FMRX_TRY(fe_launch(pl->fe, d_iq, n, hist, pl->ifb.p, s, pl->force_generic));
@@ -347,40 +356,35 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
     }
     pl->prev_cur ^= 1;
     pl->prev_override = false;
-    if (pl->profiling) FMRX_HIP(hipEventRecord(ev[1], s));
-    const int hb = pl->fe.hist_bytes;
-    uint8_t *hist_next = pl->fe_hist[pl->fe_cur ^ 1].p;
     pl->fe_cur ^= 1;
+    if (pl->profiling) FMRX_HIP(hipEventRecord(ev[1], s));
+    if (!hist_done)
+        hipLaunchKernelGGL(hist_update_kernel, dim3((hb + 255) / 256), dim3(256), 0, s, hist, d_iq,
+                           static_cast<long>(n_bytes), hb, hist_next);
+    // a block shorter than the history keeps its own front valid, so that "tail of the previous
+    // buffer" stays a contiguous Hd samples for whoever comes next
+    if (n_if < static_cast<size_t>(pl->Hd)) FMRX_TRY(materialise_history());
+    pl->demod_last = cur;
+    pl->demod_n_last = n_if;
 
     if (pl->channels == 1 && !pl->resample) {
         // ---- RF_MONO, modes 0/1: audio FIR + decimate + PCM in one kernel (project.cpp:346;
         //      threadMonoOnly.cpp:185-191), straight into the caller's buffers ----
         float *dst = d_audio_f32 ? d_audio_f32 : pl->mono.p;
-        FMRX_TRY(audio_fir_launch(pl->audio, demod, n_if, 0, dst, d_pcm16, pcm_policy, s, pl->force_generic));
+        const bool fast = audio_fast_available(pl->audio, demod) && !pl->force_generic;
+        if (!fast && !pl->demod_front[cur]) FMRX_TRY(materialise_history());
+        FMRX_TRY(audio_fir_launch(pl->audio, demod, fast ? hist_end : nullptr, n_if, 0, dst, d_pcm16, pcm_policy, s,
+                                  pl->force_generic));
         pl->last_mono = dst;
-        if (pl->profiling) FMRX_HIP(hipEventRecord(ev[2], s));
-        // carried state for the next block: I_state/Q_state as raw bytes (filter.cpp:182-187) and
-        // state_mono as the demod tail, one launch
-        if (n_if >= static_cast<size_t>(pl->Hd)) {
-            const int nthr = hb > pl->Hd ? hb : pl->Hd;
-            hipLaunchKernelGGL(state_carry_kernel, dim3((nthr + 255) / 256), dim3(256), 0, s, hist, d_iq,
-                               static_cast<long>(n_bytes), hb, hist_next, pl->demod.p, pl->Hd, static_cast<long>(n_if));
-        } else {
-            hipLaunchKernelGGL(hist_update_kernel, dim3((hb + 255) / 256), dim3(256), 0, s, hist, d_iq,
-                               static_cast<long>(n_bytes), hb, hist_next);
-            FMRX_TRY(carry_history(pl, pl->demod.p, pl->Hd, n_if, s));
-        }
         if (pl->profiling) {
+            FMRX_HIP(hipEventRecord(ev[2], s));
             FMRX_HIP(hipEventRecord(ev[3], s));
             pl->calls++;
         }
         return FMRX_OK;
     }
 
-    // I_state/Q_state <- last samples of the block (filter.cpp:182-187), kept as raw bytes
-    hipLaunchKernelGGL(hist_update_kernel, dim3((hb + 255) / 256), dim3(256), 0, s, hist, d_iq,
-                       static_cast<long>(n_bytes), hb, hist_next);
-
+    if (!pl->demod_front[cur]) FMRX_TRY(materialise_history());
     float *out_l = pl->mono.p, *out_r = nullptr;
     pl->last_mono = pl->mono.p;
     if (pl->channels == 1) {
@@ -417,7 +421,6 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
         out_l = pl->left.p;
         out_r = pl->right.p;
     }
-    FMRX_TRY(carry_history(pl, pl->demod.p, pl->Hd, n_if, s));
 
     // ---- outputs ----
     if (d_audio_f32) {
@@ -470,7 +473,7 @@ int fmrx_pipeline_read_tap(fmrx_pipeline *pl, int which, float *out, size_t *n)
         // last n_if samples of [Hd | n_if] only until the next block; read it from the
         // tail copy kept in front when the block is shorter than that -- simplest: the
         // block region itself is still intact (carry copies, it does not move)
-        src = pl->demod.p + pl->Hd; cnt = n_if; break;
+        src = pl->demod_buf[pl->demod_last].p + pl->Hd; cnt = n_if; break;
     case FMRX_TAP_MONO: src = pl->last_mono ? pl->last_mono : pl->mono.p; cnt = n_au; break;
     case FMRX_TAP_CARRIER: if (st) { src = pl->carrier.p; cnt = n_if; } break;
     case FMRX_TAP_STEREO_BPF: if (st) { src = pl->bpf.p; cnt = n_if; } break;
@@ -520,7 +523,9 @@ int fmrx_pipeline_get_state(fmrx_pipeline *pl, float *state, size_t n)
     FMRX_HIP(hipMemcpy(o, pl->prev_iq[pl->prev_cur].p, 2 * sizeof(float), hipMemcpyDeviceToHost));
     o += 2;
     std::vector<float> dh(pl->Hd);
-    FMRX_HIP(hipMemcpy(dh.data(), pl->demod.p, pl->Hd * sizeof(float), hipMemcpyDeviceToHost));
+    // the carried demod history = the last Hd samples of [front | block] of the buffer used last
+    FMRX_HIP(hipMemcpy(dh.data(), pl->demod_buf[pl->demod_last].p + pl->demod_n_last, pl->Hd * sizeof(float),
+                       hipMemcpyDeviceToHost));
     // the demod history is shared by every consumer of demod; each reference
     // state vector is a window of it
     const float *dend = dh.data() + pl->Hd;  // one past demod[-1]
@@ -576,7 +581,10 @@ int fmrx_pipeline_set_state(fmrx_pipeline *pl, const float *state, size_t n)
     } else {
         std::memcpy(dend - pl->Ha, s_mono, pl->Ha * sizeof(float));
     }
-    FMRX_HIP(hipMemcpy(pl->demod.p, dh.data(), pl->Hd * sizeof(float), hipMemcpyHostToDevice));
+    FMRX_HIP(hipMemcpy(pl->demod_buf[0].p, dh.data(), pl->Hd * sizeof(float), hipMemcpyHostToDevice));
+    pl->demod_last = 0;
+    pl->demod_n_last = 0;
+    pl->demod_front[0] = true;
     pl->prev_override = true;   // the fused front end would otherwise recompute IF[-1] from the byte history
     pl->pll_warm = false;
     if (pl->channels == 2) FMRX_HIP(hipMemset(pl->pll_scratch.p + 5, 0, 3 * sizeof(float)));
