@@ -73,8 +73,19 @@ struct FePlan {
     int hist_bytes = 0;        // bytes of u8 history the kernel reads before the block (multiple of 16)
     DevBuf<float> table;       // fast-path table
     DevBuf<float> h;           // plain taps (generic path)
+    // matrix-core kernel (kernels_fe_mfma.hip): taps as int8 digit fragments + the scale that undoes them
+    bool mfma = false;
+    DevBuf<int32_t> a_img;
+    float scale_lo = 0.0f;
 };
+constexpr int kFeMfmaDigits = 3;   // base-256 digits per tap: 24-bit fixed point
 int fe_plan_init(FePlan &pl, const float *h, int taps, int decim);
+// Matrix-core front end + discriminator: same contract as fe_demod_launch, but the IF sample in
+// front of the block (d_prev, float2) is always taken from the caller.
+int fe_mfma_plan_init(FePlan &pl, const float *h, int taps, int decim);
+bool fe_mfma_available(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist);
+int fe_mfma_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist, const float *d_prev,
+                   float *d_demod, float *d_if, float *d_prev_out, uint8_t *d_hist_next, hipStream_t stream);
 // d_hist: hist_bytes bytes whose LAST 2*(taps-1) hold the previous samples.
 // Writes n_samples/decim float2 (I,Q) to d_if.
 int fe_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist, float *d_if,

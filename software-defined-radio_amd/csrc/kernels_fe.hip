@@ -589,7 +589,7 @@ int fe_plan_init(FePlan &pl, const float *h, int taps, int decim)
         FMRX_TRY(pl.table.alloc(tab.size()));
         FMRX_HIP(hipMemcpy(pl.table.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
     }
-    return FMRX_OK;
+    return fe_mfma_plan_init(pl, h, taps, decim);
 }
 
 int fe_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist, float *d_if,

@@ -85,6 +85,14 @@ __global__ void hist_update_kernel(const uint8_t *__restrict__ old_hist, const u
     new_hist[i] = src >= 0 ? x[src] : old_hist[hb + src];
 }
 
+// FMRX_FE_VARIANT=valu selects the vector-ALU fused kernel (kernels_fe.hip) instead of the
+// matrix-core one; read per call so one process can A/B them.
+bool fe_variant_mfma()
+{
+    const char *e = std::getenv("FMRX_FE_VARIANT");
+    return !(e && std::strcmp(e, "valu") == 0);
+}
+
 int n_if_of(const fmrx_pipeline *pl, size_t n_bytes) { return static_cast<int>((n_bytes / 2) / pl->p.rf_decim); }
 
 size_t n_audio_of(const fmrx_pipeline *pl, size_t n_bytes)
@@ -342,7 +350,13 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
     const float *prev = pl->prev_iq[pl->prev_cur].p;
     float *prev_next = pl->prev_iq[pl->prev_cur ^ 1].p;
     bool hist_done = false;
-    if (!pl->force_generic && fe_fused_available(pl->fe, d_iq, n)) {
+    if (!pl->force_generic && fe_variant_mfma() && fe_mfma_available(pl->fe, d_iq, n, hist)) {
+        // matrix-core kernel: int8 MFMA FIR + discriminator, HBM-bound (kernels_fe_mfma.hip)
+        hist_done = n_bytes >= static_cast<size_t>(hb);
+        FMRX_TRY(fe_mfma_launch(pl->fe, d_iq, n, hist, prev, demod, pl->keep_if ? pl->ifb.p : nullptr, prev_next,
+                                hist_done ? hist_next : nullptr, s));
+        pl->if_valid = pl->keep_if;
+    } else if (!pl->force_generic && fe_fused_available(pl->fe, d_iq, n)) {
         // one kernel; the IF stream is written only when somebody asked to look at it, and the kernel
         // also leaves the stream's last bytes (I_state/Q_state, filter.cpp:182-187) for the next block
         hist_done = n_bytes >= static_cast<size_t>(hb);
