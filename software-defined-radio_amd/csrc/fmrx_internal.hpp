@@ -80,8 +80,7 @@ struct FePlan {
 };
 constexpr int kFeMfmaDigits = 3;   // base-256 digits per tap: 24-bit fixed point
 int fe_plan_init(FePlan &pl, const float *h, int taps, int decim);
-// Matrix-core front end + discriminator: same contract as fe_demod_launch, but the IF sample in
-// front of the block (d_prev, float2) is always taken from the caller.
+// Matrix-core front end + discriminator: same contract as fe_demod_launch.
 int fe_mfma_plan_init(FePlan &pl, const float *h, int taps, int decim);
 bool fe_mfma_available(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist);
 int fe_mfma_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist, const float *d_prev,

@@ -16,7 +16,7 @@
 //
 // Shape.  One MFMA tile = v_mfma_i32_16x16x64_i8:
 //   rows    (M=16) = 8 consecutive IF outputs x {I, Q}
-//   columns (N=16) = 16 consecutive groups of 8 outputs  ->  128 outputs per tile
+//   columns (N=16) = 16 consecutive groups of 8 outputs (the first one belongs to the previous tile)
 //   K              = the raw interleaved byte stream of a column's window; a row's taps sit on
 //                    every other byte (I rows on even bytes, Q rows on odd bytes), so the
 //                    de-interleave costs nothing and the B operand is the input, untouched
@@ -25,11 +25,16 @@
 // Since every lane holds 16 consecutive K bytes of its row/column in both operands, the product
 // does not depend on how the hardware numbers k inside a lane.
 //
-// Data movement.  Each wave owns a contiguous run of tiles and streams its bytes once:
-// LDS-DMA (global_load_lds_dwordx4, 1 KiB per instruction, no VGPRs) fills a wave-private ring
-// of P+1 tile slots, P tiles ahead of the MFMAs; the B fragments are ds_read_b128 at a 16*D-byte
-// column stride.  No workgroup barrier, no de-interleave pass, every input byte read once
-// (+ FRONT bytes per wave), every output written once.
+// The discriminator needs the IF sample in front of each output.  Inside a tile that is a lane
+// shuffle; across tiles there is no carry: column 0 of every tile recomputes the previous tile's
+// last column (1/16 more MFMA work, which is not the bound), so tiles are independent.
+//
+// Data movement.  Tiles are dealt round-robin to the resident waves, so the chip sweeps the input
+// front to back.  LDS-DMA (global_load_lds_dwordx4, 1 KiB per instruction, no VGPRs) fills a
+// wave-private ring of P+1 tile slots, P tiles ahead of the MFMAs; the B fragments are
+// ds_read_b128 at a 16*D-byte column stride.  No workgroup barrier, no de-interleave pass; a
+// tile's window overlaps its neighbour's by LEAD + K padding bytes (L2 hits), outputs are
+// written once.
 #include "device_math.hpp"
 #include "fmrx_internal.hpp"
 
@@ -44,30 +49,28 @@ using f4 = float __attribute__((ext_vector_type(4)));
 
 constexpr int iclamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-template <int T, int D>
+template <int T, int D, int PF = 0>
 struct MfCfg {
     static constexpr int COL_OUT = 8;                              // outputs per column (x2 channels = 16 rows)
-    static constexpr int COLS = 16;
-    static constexpr int TILE_OUT = COL_OUT * COLS;                // 128
+    static constexpr int COLS = 16;                                // column 0 repeats the previous tile's last column:
+    static constexpr int TILE_OUT = COL_OUT * (COLS - 1);          //   it only supplies the IF sample in front -> 120 new outputs
     static constexpr int COL_BYTES = 2 * D * COL_OUT;              // input bytes per column = column stride
-    static constexpr int TILE_BYTES = COL_BYTES * COLS;            // 256*D
+    static constexpr int STRIDE_BYTES = COL_BYTES * (COLS - 1);    // input bytes from one tile to the next
     static constexpr int FRONT = (2 * (T - 1) + 15) / 16 * 16;     // bytes of a column's window in front of its first output's sample
     static constexpr int WIN = FRONT + 2 * D * (COL_OUT - 1) + 2;  // bytes a column's rows touch
     static constexpr int KSTEPS = (WIN + 63) / 64;
     static constexpr int NDIG = kFeMfmaDigits;
-    static constexpr int NPF = TILE_BYTES / 1024;                  // full 1 KiB DMA pieces per tile
-    static constexpr int REM_LANES = (TILE_BYTES % 1024) / 16;     // lanes of the last, partial piece
+    static constexpr int LEAD = COL_BYTES + FRONT;                 // a tile's window starts this far in front of its first new output
+    static constexpr int TILE_WIN = COL_BYTES * (COLS - 1) + 64 * KSTEPS;   // bytes a tile reads
+    static constexpr int NPF = TILE_WIN / 1024;                    // full 1 KiB DMA pieces per tile
+    static constexpr int REM_LANES = (TILE_WIN % 1024) / 16;       // lanes of the last, partial piece
     static constexpr int NP = NPF + (REM_LANES ? 1 : 0);
-    static constexpr int P = iclamp(8192 / TILE_BYTES, 2, 10);     // tiles in flight ahead of the one being multiplied
+    static constexpr int SLOT = NP * 1024;                         // LDS bytes per tile
+    static constexpr int P = PF ? PF : iclamp(8192 / TILE_WIN, 2, 8);   // tiles in flight beyond the one being multiplied
     static constexpr int NSLOT = P + 1;
-    static constexpr int RING = NSLOT * TILE_BYTES;                // bytes of LDS per wave
-    static constexpr int PIECE0 = NPF ? 1024 : TILE_BYTES;
-    // a tile reads its own slot and the head of the next one: that head must be one DMA piece
-    static_assert(WIN - COL_BYTES <= PIECE0, "window overlap must fit the next slot's first piece");
-    static_assert(64 * KSTEPS - COL_BYTES <= RING - TILE_BYTES, "K padding laps the ring");
-    static_assert(TILE_BYTES % 16 == 0 && COL_BYTES % 16 == 0, "16-byte fragments");
-    // vmcnt budget: DMA pieces younger than (next slot, piece 0) in steady state
-    static constexpr int YOUNGER = (NP - 1) + NP * (P - 1);
+    static constexpr int RING = NSLOT * SLOT;                      // bytes of LDS per wave
+    static_assert(TILE_WIN % 16 == 0 && COL_BYTES % 16 == 0, "16-byte fragments");
+    static constexpr int YOUNGER = NP * P;                         // DMA pieces younger than a tile's last one, steady state
     static_assert(YOUNGER + 2 * P <= 63, "vmcnt is 6 bits");
 };
 
@@ -77,24 +80,24 @@ __device__ __forceinline__ void wait_vmcnt()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// LDS-DMA of tile slot u (bytes [u*TILE - FRONT, (u+1)*TILE - FRONT) of the block) into ring slot rs.
-// Bytes before the block come from the tail of the history; addresses past the block are clamped
-// to its last 16 bytes (what lands there only ever meets zero taps or outputs that are not stored),
-// so every instruction is issued with its full, compile-time set of lanes: the counted waits
-// below depend on that.
-template <class C>
-__device__ __forceinline__ void mf_dma_slot(const uint8_t *__restrict__ x, const uint8_t *__restrict__ hist_end, long n_bytes,
-                                            int u, uint8_t *ring, int rs, int lane)
+// LDS-DMA of one tile's window (TILE_WIN bytes from STRIDE_BYTES*tile - LEAD of the block) into ring
+// slot rs.  Bytes before the block come from the tail of the history; addresses past the block are
+// clamped to its last 16 bytes (what lands there only ever meets zero taps or outputs that are not
+// stored), so every instruction is issued with its full, compile-time set of lanes: the counted
+// waits below depend on that.
+template <class C, int AUX = 0>
+__device__ __forceinline__ void mf_dma_tile(const uint8_t *__restrict__ x, const uint8_t *__restrict__ hist_end, long n_bytes,
+                                            int tile, uint8_t *ring, int rs, int lane)
 {
-    const long s0 = static_cast<long>(u) * C::TILE_BYTES - C::FRONT;   // wave-uniform
-    uint8_t *dst = ring + rs * C::TILE_BYTES;
+    const long s0 = static_cast<long>(tile) * C::STRIDE_BYTES - C::LEAD;   // wave-uniform
+    uint8_t *dst = ring + rs * C::SLOT;
     if (s0 >= 0 && s0 + C::NP * 1024L <= n_bytes) {
         const uint8_t *base = x + s0;   // scalar base, lane*16 + k*1024 offsets
 #pragma unroll
         for (int k = 0; k < C::NP; k++)
             if (k < C::NPF || lane < C::REM_LANES)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + (lane * 16 + k * 1024)),
-                                                 (__attribute__((address_space(3))) void *)(dst + k * 1024), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)(dst + k * 1024), 16, 0, AUX);
     } else {
 #pragma unroll
         for (int k = 0; k < C::NP; k++)
@@ -103,37 +106,34 @@ __device__ __forceinline__ void mf_dma_slot(const uint8_t *__restrict__ x, const
                 if (off > n_bytes - 16) off = n_bytes - 16;
                 const uint8_t *src = off < 0 ? hist_end + off : x + off;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(dst + k * 1024), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)(dst + k * 1024), 16, 0, AUX);
             }
     }
 }
 
-template <int T, int D, int MINB>
+// DBG (tuning variants behind FMRX_FE_MFMA_TUNE, never dispatched by default):
+// 1 = no output stores, 2 = no MFMA work, 8 = non-temporal DMA
+template <int T, int D, int MINB, int PF, int DBG = 0>
 __global__ __launch_bounds__(256, MINB) void fe_mfma_kernel(
     const uint8_t *__restrict__ x, const uint8_t *__restrict__ hist_end, long n_bytes, const i4 *__restrict__ a_img,
     float scale_lo, const float2 *__restrict__ prev_in, float *__restrict__ demod, float *__restrict__ y_if,
-    float2 *__restrict__ prev_out, long n_out, int n_tiles, int tiles_per_wave, uint8_t *__restrict__ hist_next,
-    int hist_bytes)
+    float2 *__restrict__ prev_out, long n_out, int n_tiles, uint8_t *__restrict__ hist_next, int hist_bytes)
 {
-    using C = MfCfg<T, D>;
+    using C = MfCfg<T, D, PF>;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     uint8_t *ring = lds_raw + wave * C::RING;                 // this wave's private ring
-    const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * 4 + wave);
+    // tiles are dealt round-robin over all resident waves, the four waves of a workgroup taking four
+    // neighbours: at any moment the chip is reading one contiguous stretch of the input
+    const int tstep = static_cast<int>(gridDim.x) * 4;
+    int tile = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * 4 + wave);
 
     // the stream's last bytes become the next block's history (I_state/Q_state of the reference,
     // src/filter.cpp:182-187): one wave copies them; host guarantees n_bytes >= hist_bytes
-    if (hist_next && wid == 0)
+    if (hist_next && tile == 0)
         for (int i = lane; i < hist_bytes; i += 64) hist_next[i] = x[n_bytes - hist_bytes + i];
-
-    const int t0 = wid * tiles_per_wave;                      // this wave's tiles: [t0, t1)
-    const int t1 = t0 + tiles_per_wave < n_tiles ? t0 + tiles_per_wave : n_tiles;
-    if (t0 >= t1) return;
-    // The discriminator needs the IF sample in front of the run.  A run that starts the block takes
-    // it from the carried state (prev_i/prev_q, src/project.cpp:122-126); any other run first
-    // multiplies the tile before its own ("dry": nothing stored).
-    const int tb = t0 > 0 ? t0 - 1 : 0;
+    if (tile >= n_tiles) return;
 
     // taps: KSTEPS x NDIG fragments, resident for the whole kernel
     i4 a[C::KSTEPS][C::NDIG];
@@ -141,11 +141,14 @@ __global__ __launch_bounds__(256, MINB) void fe_mfma_kernel(
     for (int j = 0; j < C::KSTEPS; j++)
 #pragma unroll
         for (int d = 0; d < C::NDIG; d++) a[j][d] = a_img[(j * C::NDIG + d) * 64 + lane];
-    float ci = 0.0f, cq = 0.0f;
-    if (t0 == 0) {
+    // The IF sample in front of the block: recomputed from the history like any other (column 0 of
+    // tile 0), unless the caller carries one that the history does not explain (after set_state).
+    float ovi = 0.0f, ovq = 0.0f;
+    const bool override_prev = prev_in != nullptr;
+    if (override_prev) {
         const float2 p = *prev_in;
-        ci = p.x;
-        cq = p.y;
+        ovi = p.x;
+        ovq = p.y;
     }
     // everything an ordinary load returns is in registers before the first DMA is issued (the
     // compiler drains vmcnt to 0 at the use of a plain load: keep that out of the streaming loop)
@@ -154,32 +157,28 @@ __global__ __launch_bounds__(256, MINB) void fe_mfma_kernel(
     for (int j = 0; j < C::KSTEPS; j++)
 #pragma unroll
         for (int d = 0; d < C::NDIG; d++) asm volatile("" : "+v"(a[j][d]));
-    asm volatile("" : "+v"(ci), "+v"(cq));
+    asm volatile("" : "+v"(ovi), "+v"(ovq));
 
-    {
-        int rs = 0;
-        for (int u = tb; u <= tb + C::P && u <= t1; u++) {
-            mf_dma_slot<C>(x, hist_end, n_bytes, u, ring, rs, lane);
-            rs++;
-        }
-    }
+#pragma unroll
+    for (int k = 0; k < C::P; k++)
+        if (tile + k * tstep < n_tiles) mf_dma_tile<C, (DBG & 8) ? 2 : 0>(x, hist_end, n_bytes, tile + k * tstep, ring, k, lane);
 
     const int col = lane & 15, g = lane >> 4;
     const int lane_off = C::COL_BYTES * col + 16 * g;
     const float scale_hi = scale_lo * 65536.0f;
     const bool with_if = y_if != nullptr;
     const int src_lane = lane >= 16 ? lane - 16 : lane + 47;   // who holds the output in front of this lane's first
-    int slot = 0;
-    for (int t = tb; t < t1; t++) {
-        // ---- tile t's slot and the first piece of slot t+1 have landed -------------------
-        // vmcnt counts in issue order.  With every slot up to t+P issued, the operations younger
-        // than (slot t+1, piece 0) are YOUNGER DMA pieces plus the stores of the P iterations in
-        // between: exactly one demod store (+ one IF store) each once those were interior,
-        // non-dry tiles.  Under-counting stores only waits longer; near the run's end wait for all.
-        const bool steady = t + C::P <= t1;
-        const bool warm = t - C::P >= t0;
+    int slot = 0, fill = C::P;                                 // ring slot of this tile / of the tile P ahead
+    for (int it = 0; tile < n_tiles; tile += tstep, it++) {
+        const bool steady = tile + C::P * tstep < n_tiles;     // wave-uniform
+        if (steady) mf_dma_tile<C, (DBG & 8) ? 2 : 0>(x, hist_end, n_bytes, tile + C::P * tstep, ring, fill, lane);
+        // ---- this tile's window has landed -------------------------------------------------
+        // vmcnt counts in issue order.  The operations younger than this tile's last piece are the
+        // YOUNGER pieces of the P tiles behind it and the stores of the P iterations in between:
+        // exactly one demod store (+ one IF store) each (those tiles came before this one, so they
+        // were full).  Under-counting stores only waits longer; without P tiles behind, wait for all.
         if (steady) {
-            if (!warm) wait_vmcnt<C::YOUNGER>();
+            if (it < C::P) wait_vmcnt<C::YOUNGER>();
             else if (with_if) wait_vmcnt<C::YOUNGER + 2 * C::P>();
             else wait_vmcnt<C::YOUNGER + C::P>();
         } else {
@@ -189,18 +188,13 @@ __global__ __launch_bounds__(256, MINB) void fe_mfma_kernel(
         __builtin_amdgcn_wave_barrier();
 
         // ---- B fragments: 16 consecutive window bytes per lane and K-step ------------------
-        const int base = slot * C::TILE_BYTES + lane_off;
+        const uint8_t *bsrc = ring + slot * C::SLOT + lane_off;
         i4 b[C::KSTEPS];
 #pragma unroll
-        for (int j = 0; j < C::KSTEPS; j++) {
-            int adr = base + 64 * j;
-            adr = adr >= C::RING ? adr - C::RING : adr;
-            b[j] = *reinterpret_cast<const i4 *>(ring + adr);
-        }
+        for (int j = 0; j < C::KSTEPS; j++) b[j] = *reinterpret_cast<const i4 *>(bsrc + 64 * j);
         __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0): the slot may be refilled
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (t + C::P + 1 <= t1) mf_dma_slot<C>(x, hist_end, n_bytes, t + C::P + 1, ring, slot, lane);
 
         // ---- 3 exact int8 products per K-step ------------------------------------------------
         i4 acc[C::NDIG];
@@ -209,6 +203,10 @@ __global__ __launch_bounds__(256, MINB) void fe_mfma_kernel(
 #pragma unroll
         for (int j = 0; j < C::KSTEPS; j++) {
             const i4 bs = b[j] ^ static_cast<int>(0x80808080u);   // u8 ^ 0x80 = (u8 - 128) as int8
+            if (DBG & 2) {
+                acc[j % C::NDIG] += bs;
+                continue;
+            }
 #pragma unroll
             for (int d = 0; d < C::NDIG; d++) acc[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[j][d], bs, acc[d], 0, 0, 0);
         }
@@ -223,17 +221,15 @@ __global__ __launch_bounds__(256, MINB) void fe_mfma_kernel(
             v[k] = C::NDIG >= 3 ? __builtin_fmaf(static_cast<float>(acc[2][k]), scale_hi, flo) : flo;
         }
         float pi = __shfl(v[2], src_lane, 64), pq = __shfl(v[3], src_lane, 64);
-        if (lane == 0) {
-            pi = ci;
-            pq = cq;
+        const long o = static_cast<long>(tile) * C::TILE_OUT + C::COL_OUT * (col - 1) + 2 * g;
+        if (override_prev && o == 0) {
+            pi = ovi;
+            pq = ovq;
         }
-        ci = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[2]), 63));
-        cq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[3]), 63));
         const float d0 = demod_fast(v[0], v[1], pi, pq);
         const float d1 = demod_fast(v[2], v[3], v[0], v[1]);
 
-        const long o = static_cast<long>(t) * C::TILE_OUT + C::COL_OUT * col + 2 * g;
-        if (t >= t0 && o < n_out) {
+        if (col > 0 && o < n_out && (!(DBG & 1) || d0 == 1234.5f)) {
             if (o + 1 < n_out) {
                 *reinterpret_cast<f2 *>(demod + o) = (f2){d0, d1};
                 if (with_if) *reinterpret_cast<f4 *>(y_if + 2 * o) = (f4){v[0], v[1], v[2], v[3]};
@@ -245,16 +241,16 @@ __global__ __launch_bounds__(256, MINB) void fe_mfma_kernel(
             }
         }
         slot = slot + 1 == C::NSLOT ? 0 : slot + 1;
+        fill = fill + 1 == C::NSLOT ? 0 : fill + 1;
     }
 }
 
-template <int T, int D>
+template <int T, int D, int MINB = 2, int PF = 0, int DBG = 0>
 int launch_mfma(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist, const float *d_prev,
                 float *d_demod, float *d_if, float *d_prev_out, uint8_t *d_hist_next, hipStream_t stream)
 {
-    using C = MfCfg<T, D>;
-    constexpr int MINB = 2;                                    // workgroups per CU the register budget is set for
-    if (C::FRONT > pl.hist_bytes) return fail(FMRX_EINVAL, "fe_mfma: history too short");
+    using C = MfCfg<T, D, PF>;
+    if (C::LEAD > pl.hist_bytes) return fail(FMRX_EINVAL, "fe_mfma: history too short");
     const long n_out = static_cast<long>(n_samples / D);
     const long n_tiles = (n_out + C::TILE_OUT - 1) / C::TILE_OUT;
     long wgs_per_cu = (160 * 1024) / (4L * C::RING);
@@ -263,18 +259,12 @@ int launch_mfma(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const u
         const long v = std::atol(e);
         if (v >= 1 && v < wgs_per_cu) wgs_per_cu = v;
     }
-    // a run shorter than ~8 tiles spends too much on its dry tile: fewer, longer runs on small blocks
-    const long max_waves = 256 * wgs_per_cu * 4;
-    long waves = (n_tiles + 7) / 8;
-    if (waves > max_waves) waves = max_waves;
-    if (waves < 1) waves = 1;
-    const long tpw = (n_tiles + waves - 1) / waves;
-    const long grid = ((n_tiles + tpw - 1) / tpw + 3) / 4;
-    hipLaunchKernelGGL((fe_mfma_kernel<T, D, MINB>), dim3(static_cast<unsigned>(grid)), dim3(256), 4 * C::RING, stream, d_iq,
+    const long want = (n_tiles + 3) / 4;
+    const long grid = want < 256 * wgs_per_cu ? want : 256 * wgs_per_cu;
+    hipLaunchKernelGGL((fe_mfma_kernel<T, D, MINB, PF, DBG>), dim3(static_cast<unsigned>(grid)), dim3(256), 4 * C::RING, stream, d_iq,
                        d_hist + pl.hist_bytes, static_cast<long>(2 * n_samples), reinterpret_cast<const i4 *>(pl.a_img.p),
                        pl.scale_lo, reinterpret_cast<const float2 *>(d_prev), d_demod, d_if,
-                       reinterpret_cast<float2 *>(d_prev_out), n_out, static_cast<int>(n_tiles), static_cast<int>(tpw),
-                       d_hist_next, pl.hist_bytes);
+                       reinterpret_cast<float2 *>(d_prev_out), n_out, static_cast<int>(n_tiles), d_hist_next, pl.hist_bytes);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FMRX_EHIP, "launch fe_mfma_kernel<%d,%d>: %s", T, D, hipGetErrorString(e));
     return FMRX_OK;
@@ -348,7 +338,20 @@ int fe_mfma_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, cons
                    float *d_demod, float *d_if, float *d_prev_out, uint8_t *d_hist_next, hipStream_t stream)
 {
     if (n_samples / pl.decim == 0) return FMRX_OK;
-    if (!d_prev || !d_demod) return fail(FMRX_EINVAL, "fe_mfma_launch: null argument");
+    if (!d_demod) return fail(FMRX_EINVAL, "fe_mfma_launch: null argument");
+    if (const char *e = std::getenv("FMRX_FE_MFMA_TUNE")) {   // "<workgroups per CU><tiles in flight>", (101,10) only
+        const int v = std::atoi(e);
+#define Y(B_, P_) \
+    if (pl.taps == 101 && pl.decim == 10 && v == B_ * 10 + P_) \
+        return launch_mfma<101, 10, B_, P_>(pl, d_iq, n_samples, d_hist, d_prev, d_demod, d_if, d_prev_out, d_hist_next, stream);
+        Y(2, 2) Y(2, 3) Y(2, 4) Y(3, 3) Y(4, 3) Y(1, 3)
+#undef Y
+#define Y(G_) \
+    if (pl.taps == 101 && pl.decim == 10 && v == G_ * 100 + 23) \
+        return launch_mfma<101, 10, 2, 3, G_>(pl, d_iq, n_samples, d_hist, d_prev, d_demod, d_if, d_prev_out, d_hist_next, stream);
+        Y(1) Y(2) Y(3) Y(8)
+#undef Y
+    }
 #define X(T_, D_) \
     if (pl.taps == T_ && pl.decim == D_) \
         return launch_mfma<T_, D_>(pl, d_iq, n_samples, d_hist, d_prev, d_demod, d_if, d_prev_out, d_hist_next, stream);

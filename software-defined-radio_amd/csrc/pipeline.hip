@@ -353,7 +353,8 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
     if (!pl->force_generic && fe_variant_mfma() && fe_mfma_available(pl->fe, d_iq, n, hist)) {
         // matrix-core kernel: int8 MFMA FIR + discriminator, HBM-bound (kernels_fe_mfma.hip)
         hist_done = n_bytes >= static_cast<size_t>(hb);
-        FMRX_TRY(fe_mfma_launch(pl->fe, d_iq, n, hist, prev, demod, pl->keep_if ? pl->ifb.p : nullptr, prev_next,
+        FMRX_TRY(fe_mfma_launch(pl->fe, d_iq, n, hist, pl->prev_override ? prev : nullptr, demod,
+                                pl->keep_if ? pl->ifb.p : nullptr, prev_next,
                                 hist_done ? hist_next : nullptr, s));
         pl->if_valid = pl->keep_if;
     } else if (!pl->force_generic && fe_fused_available(pl->fe, d_iq, n)) {

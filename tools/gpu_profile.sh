@@ -21,3 +21,4 @@ pmc pmc_grbm GRBM_GUI_ACTIVE GRBM_COUNT
 find $OUT -name "*.csv" | head -40
 python3 tools/prof_summary.py $OUT > gpurun_out/prof_summary.txt 2>&1
 cat gpurun_out/prof_summary.txt | head -80
+rocprofv3 -L > gpurun_out/counters.txt 2>&1 || true
