@@ -67,6 +67,7 @@ struct DevBuf {
 // ---- front-end fast path (kernels_fe.hip) -----------------------------------
 // Device-side tap table for the register-window FIR: phase-major, padded,
 // pre-scaled.  See kernels_fe.hip for the layout.
+struct AudioPlan;
 struct FePlan {
     int taps = 0, decim = 0;
     bool fast = false;         // a specialised kernel exists for (taps, decim)
@@ -106,7 +107,17 @@ struct AudioPlan {
     bool fast = false;
     DevBuf<float> table;
     DevBuf<float> h;
+    DevBuf<float> mfma_table;  // Toeplitz image for the fused mono kernel (kernels_fe_mfma.hip)
 };
+// Fused mono chain (modes 0/1): u8 I/Q -> audio / PCM in one kernel; the discriminator output stays
+// on chip except its last tail_keep samples, written to d_demod_tail[n_if - tail_keep .. n_if) for the
+// next block.  d_dhist_end: one past the previous block's last discriminator sample; d_prev: its
+// last IF sample (float2).
+int audio_mfma_table_init(AudioPlan &pl, const float *h, int taps, int decim);
+bool mono_fused_available(const FePlan &fe, const AudioPlan &au, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist);
+int mono_fused_launch(const FePlan &fe, const AudioPlan &au, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist,
+                      const float *d_prev, const float *d_dhist_end, float *d_demod_tail, int tail_keep, float *d_prev_out,
+                      float *d_audio, int16_t *d_pcm, int wrap, uint8_t *d_hist_next, hipStream_t stream);
 int audio_plan_init(AudioPlan &pl, const float *h, int taps, int decim);
 // y[k] = sum_n h[n] * x[decim*k - n - delay]; x points at the block start and
 // x[-(taps-1+delay+3) .. -1] must be readable history (the specialised kernel

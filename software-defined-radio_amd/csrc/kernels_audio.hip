@@ -267,6 +267,7 @@ int audio_plan_init(AudioPlan &pl, const float *h, int taps, int decim)
     if (pl.fast) {
         FMRX_TRY(pl.table.alloc(tab.size()));
         FMRX_HIP(hipMemcpy(pl.table.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+        FMRX_TRY(audio_mfma_table_init(pl, h, taps, decim));
     }
     return FMRX_OK;
 }

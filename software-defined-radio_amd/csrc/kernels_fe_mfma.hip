@@ -296,6 +296,276 @@ void build_image(const float *h, int s, std::vector<int8_t> &img)
             }
 }
 
+// ============================================================================================
+// Fused mono chain: RF_FrontEnd + RF_MONO of modes 0/1 (src/project.cpp:82-128, 330-350;
+// src/threadMonoOnly.cpp:185-191) in ONE kernel: u8 I/Q in, float audio and/or s16 PCM out.  The
+// discriminator output never goes to HBM (it is 1/6 of the front end's traffic and all of the audio
+// kernel's input): per input sample 2 bytes are read and 0.12 written.
+//
+// Each wave owns a contiguous run of tiles (128 IF outputs each; the IF sample in front of a tile is
+// carried in registers) and a 2048-float ring of discriminator output in LDS.  Every 2*DA tiles the
+// ring holds 256 audio outputs' worth: one batch of the audio FIR as f32 MFMAs
+// (v_mfma_f32_16x16x4_f32 = exact fmaf chains): rows = 16 consecutive audio outputs, columns = 16
+// such groups, K = the TA-1+15*DA+1 discriminator samples a column touches, A = the audio taps,
+// Toeplitz-shifted per row, resident in VGPRs.  A run that does not start the block first computes
+// the tile in front of it for the TA-1 samples of audio history ("dry": nothing stored).
+template <int T, int D, int TA, int DA>
+struct FuCfg {
+    using F = MfCfg<T, D>;
+    static constexpr int TILE_OUT = 128;
+    static constexpr int TILE_BYTES = F::COL_BYTES * 16;
+    static constexpr int NPF = TILE_BYTES / 1024;
+    static constexpr int REM_LANES = (TILE_BYTES % 1024) / 16;
+    static constexpr int NP = NPF + (REM_LANES ? 1 : 0);
+    static constexpr int P = iclamp(6144 / TILE_BYTES, 2, 8);      // tiles in flight beyond the one being multiplied
+    static constexpr int NSLOT = P + 1;
+    static constexpr int RING = NSLOT * TILE_BYTES;                // byte ring: slot t holds bytes [t*TILE - FRONT, (t+1)*TILE - FRONT)
+    static constexpr int PIECE0 = NPF ? 1024 : TILE_BYTES;
+    // a tile reads its own slot and the head of the next one: that head must be one DMA piece
+    static_assert(F::WIN - F::COL_BYTES <= PIECE0, "window overlap must fit the next slot's first piece");
+    static_assert(64 * F::KSTEPS - F::COL_BYTES <= RING - TILE_BYTES, "K padding laps the ring");
+    static constexpr int YOUNGER = (NP - 1) + NP * (P - 1);        // DMA pieces younger than (next slot, piece 0)
+    static_assert(YOUNGER <= 63, "vmcnt is 6 bits");
+    static constexpr int AB_OUT = 256;                             // audio outputs per batch
+    static constexpr int TB = AB_OUT * DA / TILE_OUT;              // tiles per batch
+    static_assert(TB * TILE_OUT == AB_OUT * DA, "batches end on tile boundaries");
+    static constexpr int AWIN = (TA - 1) + 15 * DA + 1;            // discriminator samples a column's 16 outputs touch
+    static constexpr int AK = (AWIN + 3) / 4;                      // K-steps of the 16x16x4 MFMA
+    static constexpr int DR = 2048;                                // discriminator ring, floats
+    static_assert(AB_OUT * DA + TA - 1 + 4 * AK - AWIN <= DR, "a batch's window must fit the ring");
+    static_assert(TA - 1 <= TILE_OUT - 1, "one dry tile must cover the audio history");
+    static constexpr int LDS_WAVE = RING + DR * 4;
+};
+
+template <class C, class F>
+__device__ __forceinline__ void fu_dma_slot(const uint8_t *__restrict__ x, const uint8_t *__restrict__ hist_end, long n_bytes,
+                                            int u, uint8_t *ring, int rs, int lane)
+{
+    const long s0 = static_cast<long>(u) * C::TILE_BYTES - F::FRONT;   // wave-uniform
+    uint8_t *dst = ring + rs * C::TILE_BYTES;
+    if (s0 >= 0 && s0 + C::NP * 1024L <= n_bytes) {
+        const uint8_t *base = x + s0;
+#pragma unroll
+        for (int k = 0; k < C::NP; k++)
+            if (k < C::NPF || lane < C::REM_LANES)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + (lane * 16 + k * 1024)),
+                                                 (__attribute__((address_space(3))) void *)(dst + k * 1024), 16, 0, 0);
+    } else {
+#pragma unroll
+        for (int k = 0; k < C::NP; k++)
+            if (k < C::NPF || lane < C::REM_LANES) {
+                long off = s0 + k * 1024 + lane * 16;
+                if (off > n_bytes - 16) off = n_bytes - 16;
+                const uint8_t *src = off < 0 ? hist_end + off : x + off;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(dst + k * 1024), 16, 0, 0);
+            }
+    }
+}
+
+template <int T, int D, int TA, int DA>
+__global__ __launch_bounds__(256, 2) void mono_fused_kernel(
+    const uint8_t *__restrict__ x, const uint8_t *__restrict__ hist_end, long n_bytes, const i4 *__restrict__ a_img,
+    float scale_lo, const float *__restrict__ au_img, const float2 *__restrict__ prev_in,
+    const float *__restrict__ dhist_end, float *__restrict__ demod_tail, int tail_keep, float2 *__restrict__ prev_out,
+    float *__restrict__ audio, int16_t *__restrict__ pcm, int wrap, long n_out, int n_tiles, long n_audio, int n_batches,
+    int batches_per_wave, uint8_t *__restrict__ hist_next, int hist_bytes)
+{
+    using C = FuCfg<T, D, TA, DA>;
+    using F = typename C::F;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    uint8_t *ring = lds_raw + wave * C::LDS_WAVE;
+    float *dring = reinterpret_cast<float *>(ring + C::RING);
+    const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * 4 + wave);
+
+    if (hist_next && wid == 0)   // I_state/Q_state for the next block (src/filter.cpp:182-187), as raw bytes
+        for (int i = lane; i < hist_bytes; i += 64) hist_next[i] = x[n_bytes - hist_bytes + i];
+
+    const int b0 = wid * batches_per_wave;                    // this wave's audio batches [b0, b1) = tiles [t0, t1)
+    const int b1 = b0 + batches_per_wave < n_batches ? b0 + batches_per_wave : n_batches;
+    if (b0 >= b1) return;
+    const int t0 = b0 * C::TB;
+    const int t1 = b1 * C::TB < n_tiles ? b1 * C::TB : n_tiles;
+    const int tb = t0 > 0 ? t0 - 1 : 0;
+
+    // taps of both filters, resident for the whole kernel
+    i4 a[F::KSTEPS][F::NDIG];
+#pragma unroll
+    for (int j = 0; j < F::KSTEPS; j++)
+#pragma unroll
+        for (int d = 0; d < F::NDIG; d++) a[j][d] = a_img[(j * F::NDIG + d) * 64 + lane];
+    float au[C::AK];
+#pragma unroll
+    for (int j = 0; j < C::AK; j++) au[j] = au_img[j * 64 + lane];
+    float ci = 0.0f, cq = 0.0f;
+    // the ring starts finite everywhere: padding taps are zeros, and 0 * (stale NaN bits) is not 0
+    for (int i = lane; i < C::DR; i += 64) dring[i] = 0.0f;
+    if (t0 == 0) {
+        const float2 p = *prev_in;                            // prev_i/prev_q (src/project.cpp:122-126)
+        ci = p.x;
+        cq = p.y;
+        // state_mono (src/project.cpp:346): the previous block's last TA-1 discriminator samples
+        for (int i = lane; i < TA - 1; i += 64) dring[(i - (TA - 1)) & (C::DR - 1)] = dhist_end[i - (TA - 1)];
+    }
+    // everything an ordinary load returns is in registers / LDS before the first DMA is issued (the
+    // compiler drains vmcnt to 0 at the use of a plain load: keep that out of the streaming loop)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < F::KSTEPS; j++)
+#pragma unroll
+        for (int d = 0; d < F::NDIG; d++) asm volatile("" : "+v"(a[j][d]));
+#pragma unroll
+    for (int j = 0; j < C::AK; j++) asm volatile("" : "+v"(au[j]));
+    asm volatile("" : "+v"(ci), "+v"(cq));
+
+    {
+        int rs = 0;
+        for (int u = tb; u <= tb + C::P && u <= t1; u++) {
+            fu_dma_slot<C, F>(x, hist_end, n_bytes, u, ring, rs, lane);
+            rs++;
+        }
+    }
+
+    const int col = lane & 15, g = lane >> 4;
+    const int lane_off = F::COL_BYTES * col + 16 * g;
+    const float scale_hi = scale_lo * 65536.0f;
+    const int src_lane = lane >= 16 ? lane - 16 : lane + 47;   // who holds the output in front of this lane's first
+    int slot = 0;
+    for (int t = tb; t < t1; t++) {
+        // tile t's slot and the first piece of slot t+1 have landed (vmcnt counts in issue order; the
+        // occasional output stores are not credited, which only waits longer)
+        if (t + C::P <= t1) wait_vmcnt<C::YOUNGER>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        const int base = slot * C::TILE_BYTES + lane_off;
+        i4 b[F::KSTEPS];
+#pragma unroll
+        for (int j = 0; j < F::KSTEPS; j++) {
+            int adr = base + 64 * j;
+            adr = adr >= C::RING ? adr - C::RING : adr;
+            b[j] = *reinterpret_cast<const i4 *>(ring + adr);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0): the slot may be refilled
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (t + C::P + 1 <= t1) fu_dma_slot<C, F>(x, hist_end, n_bytes, t + C::P + 1, ring, slot, lane);
+
+        i4 acc[F::NDIG];
+#pragma unroll
+        for (int d = 0; d < F::NDIG; d++) acc[d] = (i4){0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < F::KSTEPS; j++) {
+            const i4 bs = b[j] ^ static_cast<int>(0x80808080u);   // u8 ^ 0x80 = (u8 - 128) as int8
+#pragma unroll
+            for (int d = 0; d < F::NDIG; d++) acc[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[j][d], bs, acc[d], 0, 0, 0);
+        }
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int lo = acc[0][k];
+            if (F::NDIG >= 2) lo += acc[1][k] * 256;
+            const float flo = static_cast<float>(lo) * scale_lo;
+            v[k] = F::NDIG >= 3 ? __builtin_fmaf(static_cast<float>(acc[2][k]), scale_hi, flo) : flo;
+        }
+        float pi = __shfl(v[2], src_lane, 64), pq = __shfl(v[3], src_lane, 64);
+        if (lane == 0) {
+            pi = ci;
+            pq = cq;
+        }
+        ci = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[2]), 63));
+        cq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[3]), 63));
+        const float d0 = demod_fast(v[0], v[1], pi, pq);
+        const float d1 = demod_fast(v[2], v[3], v[0], v[1]);
+
+        const long o = static_cast<long>(t) * C::TILE_OUT + F::COL_OUT * col + 2 * g;
+        *reinterpret_cast<f2 *>(dring + (static_cast<int>(o) & (C::DR - 1))) = (f2){d0, d1};
+        if (t >= t0 && o + 2 > n_out - tail_keep && o < n_out) {
+            // state_mono and prev_i/prev_q for the next block (the discriminator's last samples)
+            if (o >= n_out - tail_keep) demod_tail[o] = d0;
+            if (o + 1 < n_out) demod_tail[o + 1] = d1;
+            if (prev_out && o + 2 == n_out) *prev_out = make_float2(v[2], v[3]);
+            if (prev_out && o + 1 == n_out) *prev_out = make_float2(v[0], v[1]);
+        }
+        slot = slot + 1 == C::NSLOT ? 0 : slot + 1;
+
+        // ---- a batch of 256 audio outputs is complete (or the block ends) ----------------------
+        if (t >= t0 && ((t + 1) % C::TB == 0 || t + 1 == n_tiles)) {
+            const int bt = t / C::TB;
+            const long a0 = static_cast<long>(bt) * C::AB_OUT + 16 * col;           // first output of this lane's column
+            const int ws = static_cast<int>(a0 * DA - (TA - 1)) + g;                 // its window start (+ this lane's k)
+            f4 y0 = (f4){0.0f, 0.0f, 0.0f, 0.0f}, y1 = y0;
+            __builtin_amdgcn_s_waitcnt(0xC07F);                                      // the ring writes above
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j0 = 0; j0 < C::AK; j0 += 8) {
+                float xs[8];
+#pragma unroll
+                for (int j = j0; j < j0 + 8 && j < C::AK; j++) xs[j - j0] = dring[(ws + 4 * j) & (C::DR - 1)];
+#pragma unroll
+                for (int j = j0; j < j0 + 8 && j < C::AK; j++) {
+                    if (j & 1) y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(au[j], xs[j - j0], y1, 0, 0, 0);
+                    else y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(au[j], xs[j - j0], y0, 0, 0, 0);
+                }
+            }
+            const f4 y = y0 + y1;
+            const long ao = a0 + 4 * g;                                              // this lane's 4 consecutive outputs
+            if (ao + 3 < n_audio) {
+                if (audio) *reinterpret_cast<f4 *>(audio + ao) = y;
+                if (pcm) {
+                    using s4 = short __attribute__((ext_vector_type(4)));
+                    *reinterpret_cast<s4 *>(pcm + ao) =
+                        (s4){pcm_pack(y[0], wrap), pcm_pack(y[1], wrap), pcm_pack(y[2], wrap), pcm_pack(y[3], wrap)};
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (ao + k < n_audio) {
+                        if (audio) audio[ao + k] = y[k];
+                        if (pcm) pcm[ao + k] = pcm_pack(y[k], wrap);
+                    }
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);                                      // ring reads done before it is written again
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+template <int T, int D, int TA, int DA>
+int launch_fused_mono(const FePlan &fe, const AudioPlan &au, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist,
+                      const float *d_prev, const float *d_dhist_end, float *d_demod_tail, int tail_keep, float *d_prev_out,
+                      float *d_audio, int16_t *d_pcm, int wrap, uint8_t *d_hist_next, hipStream_t stream)
+{
+    using C = FuCfg<T, D, TA, DA>;
+    if (C::F::FRONT > fe.hist_bytes) return fail(FMRX_EINVAL, "mono_fused: history too short");
+    const long n_out = static_cast<long>(n_samples / D);
+    const long n_tiles = (n_out + C::TILE_OUT - 1) / C::TILE_OUT;
+    const long n_audio = n_out / DA;
+    const long n_batches = (n_audio + C::AB_OUT - 1) / C::AB_OUT;
+    long wgs_per_cu = (160 * 1024) / (4L * C::LDS_WAVE);
+    if (wgs_per_cu > 2) wgs_per_cu = 2;
+    const long max_waves = 256 * wgs_per_cu * 4;
+    const long bpw = (n_batches + max_waves - 1) / max_waves;
+    const long grid = ((n_batches + bpw - 1) / bpw + 3) / 4;
+    hipLaunchKernelGGL((mono_fused_kernel<T, D, TA, DA>), dim3(static_cast<unsigned>(grid)), dim3(256), 4 * C::LDS_WAVE, stream,
+                       d_iq, d_hist + fe.hist_bytes, static_cast<long>(2 * n_samples), reinterpret_cast<const i4 *>(fe.a_img.p),
+                       fe.scale_lo, au.mfma_table.p, reinterpret_cast<const float2 *>(d_prev), d_dhist_end, d_demod_tail,
+                       tail_keep, reinterpret_cast<float2 *>(d_prev_out), d_audio, d_pcm, wrap, n_out, static_cast<int>(n_tiles),
+                       n_audio, static_cast<int>(n_batches), static_cast<int>(bpw), d_hist_next, fe.hist_bytes);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return fail(FMRX_EHIP, "launch mono_fused_kernel<%d,%d,%d,%d>: %s", T, D, TA, DA, hipGetErrorString(e));
+    return FMRX_OK;
+}
+
+// the reference's two integer-decimation modes: mode 0 = (rf_decim 10, audio_decim 5), mode 1 = (5, 6)
+#define FMRX_FUSED_CASES(X)                                                                         \
+    X(101, 10, 101, 5) X(151, 10, 101, 5) X(13, 10, 101, 5) X(101, 10, 13, 5) X(151, 10, 13, 5) X(13, 10, 13, 5) \
+    X(101, 5, 101, 6) X(151, 5, 101, 6) X(13, 5, 101, 6) X(101, 5, 13, 6) X(151, 5, 13, 6) X(13, 5, 13, 6)
+
 #define FMRX_FE_MFMA_CASES(X) X(13, 10) X(101, 10) X(151, 10) X(13, 5) X(101, 5) X(151, 5) X(13, 3) X(101, 3) X(151, 3)
 
 }  // namespace
@@ -358,6 +628,49 @@ int fe_mfma_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, cons
     FMRX_FE_MFMA_CASES(X)
 #undef X
     return fail(FMRX_EINVAL, "fe_mfma_launch: no kernel for taps=%d decim=%d", pl.taps, pl.decim);
+}
+
+// Toeplitz image of the audio taps in A-operand order of v_mfma_f32_16x16x4_f32: [kstep][lane], lane
+// (row i = lane&15, k = lane>>4) holds the tap that output i of a column applies to window sample
+// 4*kstep + k, i.e. h[decim*i + taps-1 - (4*kstep + k)], or 0 outside the filter.
+int audio_mfma_table_init(AudioPlan &pl, const float *h, int taps, int decim)
+{
+    const int awin = (taps - 1) + 15 * decim + 1, ak = (awin + 3) / 4;
+    std::vector<float> tab(static_cast<size_t>(ak) * 64, 0.0f);
+    for (int j = 0; j < ak; j++)
+        for (int lane = 0; lane < 64; lane++) {
+            const int k = decim * (lane & 15) + taps - 1 - (4 * j + (lane >> 4));
+            if (k >= 0 && k < taps) tab[j * 64 + lane] = h[k];
+        }
+    FMRX_TRY(pl.mfma_table.alloc(tab.size()));
+    FMRX_HIP(hipMemcpy(pl.mfma_table.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    return FMRX_OK;
+}
+
+bool mono_fused_available(const FePlan &fe, const AudioPlan &au, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist)
+{
+    if (!fe_mfma_available(fe, d_iq, n_samples, d_hist) || !au.mfma_table.p) return false;
+    for (int k = 0; k < 1; k++) {
+#define X(T_, D_, TA_, DA_) \
+    if (fe.taps == T_ && fe.decim == D_ && au.taps == TA_ && au.decim == DA_) return true;
+        FMRX_FUSED_CASES(X)
+#undef X
+    }
+    return false;
+}
+
+int mono_fused_launch(const FePlan &fe, const AudioPlan &au, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist,
+                      const float *d_prev, const float *d_dhist_end, float *d_demod_tail, int tail_keep, float *d_prev_out,
+                      float *d_audio, int16_t *d_pcm, int wrap, uint8_t *d_hist_next, hipStream_t stream)
+{
+    if (!d_prev || !d_dhist_end || !d_demod_tail) return fail(FMRX_EINVAL, "mono_fused_launch: null argument");
+#define X(T_, D_, TA_, DA_)                                                                                          \
+    if (fe.taps == T_ && fe.decim == D_ && au.taps == TA_ && au.decim == DA_)                                         \
+        return launch_fused_mono<T_, D_, TA_, DA_>(fe, au, d_iq, n_samples, d_hist, d_prev, d_dhist_end, d_demod_tail, \
+                                                   tail_keep, d_prev_out, d_audio, d_pcm, wrap, d_hist_next, stream);
+    FMRX_FUSED_CASES(X)
+#undef X
+    return fail(FMRX_EINVAL, "mono_fused_launch: no kernel for this filter shape");
 }
 
 }  // namespace fmrx

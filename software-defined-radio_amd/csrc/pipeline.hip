@@ -39,6 +39,7 @@ struct fmrx_pipeline {
     bool keep_if = false;        // materialise the IF I/Q stream (diagnostics / read_tap)
     bool prev_override = false;  // the next block takes IF[-1] from prev_iq (after set_state)
     bool if_valid = false;       // ifb holds the last block's IF samples
+    bool demod_valid = true;     // the demod buffer holds the whole last block (not just its tail: fused mono kernel)
     bool pll_warm = false;       // the PLL has seen a block since reset / set_state (its state is a locked one)
 
     hipStream_t stream = nullptr;  // used by the host-buffer entry point
@@ -91,6 +92,15 @@ bool fe_variant_mfma()
 {
     const char *e = std::getenv("FMRX_FE_VARIANT");
     return !(e && std::strcmp(e, "valu") == 0);
+}
+
+// The fused mono kernel gives each wave whole batches of 256 audio samples; below this many audio
+// samples per call there are too few batches to fill the chip and the two-kernel path is used.
+// FMRX_FUSED_MIN_AUDIO overrides (0 = always fuse when possible, a huge value = never).
+size_t fused_min_audio()
+{
+    if (const char *e = std::getenv("FMRX_FUSED_MIN_AUDIO")) return static_cast<size_t>(std::atoll(e));
+    return 256 * 256;
 }
 
 int n_if_of(const fmrx_pipeline *pl, size_t n_bytes) { return static_cast<int>((n_bytes / 2) / pl->p.rf_decim); }
@@ -350,6 +360,35 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
     const float *prev = pl->prev_iq[pl->prev_cur].p;
     float *prev_next = pl->prev_iq[pl->prev_cur ^ 1].p;
     bool hist_done = false;
+    pl->demod_valid = true;
+    if (pl->channels == 1 && !pl->resample && !pl->force_generic && !pl->keep_if && fe_variant_mfma() &&
+        n_if >= static_cast<size_t>(pl->Hd) && n_au >= fused_min_audio() &&
+        mono_fused_available(pl->fe, pl->audio, d_iq, n, hist)) {
+        // ---- RF_FrontEnd + RF_MONO of modes 0/1 in one kernel (kernels_fe_mfma.hip): the discriminator
+        //      output stays on chip; only its tail (state_mono) is written for the next block ----
+        hist_done = n_bytes >= static_cast<size_t>(hb);
+        float *dst = d_audio_f32 ? d_audio_f32 : pl->mono.p;
+        FMRX_TRY(mono_fused_launch(pl->fe, pl->audio, d_iq, n, hist, prev, hist_end, demod, pl->Hd, prev_next, dst, d_pcm16,
+                                   pcm_policy, hist_done ? hist_next : nullptr, s));
+        pl->if_valid = false;
+        pl->demod_valid = false;
+        pl->last_mono = dst;
+        pl->prev_cur ^= 1;
+        pl->prev_override = false;
+        pl->fe_cur ^= 1;
+        if (pl->profiling) FMRX_HIP(hipEventRecord(ev[1], s));
+        if (!hist_done)
+            hipLaunchKernelGGL(hist_update_kernel, dim3((hb + 255) / 256), dim3(256), 0, s, hist, d_iq,
+                               static_cast<long>(n_bytes), hb, hist_next);
+        pl->demod_last = cur;
+        pl->demod_n_last = n_if;
+        if (pl->profiling) {
+            FMRX_HIP(hipEventRecord(ev[2], s));
+            FMRX_HIP(hipEventRecord(ev[3], s));
+            pl->calls++;
+        }
+        return FMRX_OK;
+    }
     if (!pl->force_generic && fe_variant_mfma() && fe_mfma_available(pl->fe, d_iq, n, hist)) {
         // matrix-core kernel: int8 MFMA FIR + discriminator, HBM-bound (kernels_fe_mfma.hip)
         hist_done = n_bytes >= static_cast<size_t>(hb);
@@ -500,6 +539,9 @@ int fmrx_pipeline_read_tap(fmrx_pipeline *pl, int which, float *out, size_t *n)
     if (which >= FMRX_TAP_CARRIER && !st) return fail(FMRX_EINVAL, "read_tap: tap %d exists only in stereo pipelines", which);
     *n = cnt;
     if (!out || cnt == 0) return FMRX_OK;
+    if (which == FMRX_TAP_DEMOD && !pl->demod_valid)
+        return fail(FMRX_EINVAL, "read_tap: the fused mono kernel keeps the discriminator output on chip; "
+                                 "call fmrx_pipeline_set_keep_intermediates(pl, 1) before processing");
     if ((which == FMRX_TAP_IF_I || which == FMRX_TAP_IF_Q) && !pl->if_valid)
         return fail(FMRX_EINVAL, "read_tap: the IF stream is not materialised by the fused front end; call "
                                  "fmrx_pipeline_set_keep_intermediates(pl, 1) before processing");

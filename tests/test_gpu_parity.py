@@ -297,6 +297,59 @@ def test_front_end_matrix_core_kernel(fmrx, oracle, mode, rf_taps, monkeypatch):
     assert not pl.read_tap("if_i").any() and not pl.read_tap("demod").any() and not out["audio"].any()
 
 
+
+@pytest.mark.parametrize("rf_taps,au_taps", [(101, 101), (151, 101), (13, 13), (101, 13)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_fused_mono_kernel(fmrx, oracle, mode, rf_taps, au_taps, monkeypatch):
+    """Modes 0/1 mono without intermediates = ONE kernel (front end, discriminator, audio FIR as f32
+    MFMA, PCM): against the oracle, and against the two-kernel path on the same handle state (same
+    carried state bit for bit: the IF arithmetic is the same integers; audio: two float32 summation
+    orders of the same products).  Block sizes: one batch, partial batches, several waves, each
+    starting with a tile it computes only for the audio history."""
+    p = oracle.mode_params(mode, rf_taps, au_taps, 101)
+    D, A = p.rf_decim, p.audio_decim
+    unit = int(2 * D * np.lcm(A, 8))
+    sizes = [unit * k for k in (64, 7, 700, 33, 2000, 7)]
+    iq = oracle.synth_fm_u8(sum(sizes) // 2, rf_Fs=p.rf_Fs, seed=77 + mode)
+    pf = fmrx.Pipeline(mode, 1, rf_taps=rf_taps, base_audio_taps=au_taps, max_block_bytes=max(sizes))
+    pu = fmrx.Pipeline(mode, 1, rf_taps=rf_taps, base_audio_taps=au_taps, max_block_bytes=max(sizes))
+    po = oracle.pipeline(mode, 1, rf_taps, au_taps, 101)
+    off = 0
+    for nb in sizes:
+        blk = iq[off:off + nb]
+        off += nb
+        monkeypatch.setenv("FMRX_FUSED_MIN_AUDIO", "0")
+        out = pf.process(blk)
+        with pytest.raises(fmrx.FmrxError):
+            pf.read_tap("demod")          # stayed on chip
+        monkeypatch.setenv("FMRX_FUSED_MIN_AUDIO", "1000000000000")
+        outu = pu.process(blk)
+        pu.read_tap("demod")
+        ref = po.process(blk)
+        assert_audio_close(out["audio"], ref["audio"], f"fused mode {mode} taps {rf_taps}/{au_taps} block {nb}")
+        assert_pcm_close(out["pcm16"], oracle.pcm16(ref["audio"]))
+        assert np.abs(out["audio"] - outu["audio"]).max() <= 2e-6
+        bits_equal(pf.get_state(), pu.get_state(), f"carried state after block {nb}")
+    monkeypatch.delenv("FMRX_FUSED_MIN_AUDIO")
+
+
+def test_fused_mono_kernel_many_batches_per_wave(fmrx, oracle):
+    """A block large enough that every wave of the fused kernel owns several audio batches (the
+    bench's regime), against the oracle; plus silence -> exact zeros."""
+    n = 34 * 1_024_000
+    iq = oracle.synth_fm_u8(n, seed=5150)
+    pl = fmrx.Pipeline(0, 1, max_block_bytes=2 * n)
+    out = pl.process(iq)
+    ref = oracle.pipeline(0, 1).process(iq)
+    assert_audio_close(out["audio"], ref["audio"], "fused, 34 x 1,024,000 samples in one call")
+    assert_pcm_close(out["pcm16"], oracle.pcm16(ref["audio"]))
+    with pytest.raises(fmrx.FmrxError):
+        pl.read_tap("demod")
+    pl.reset()
+    out = pl.process(np.full(2 * 4_096_000, 128, np.uint8))
+    assert not out["audio"].any() and not out["pcm16"].any()
+
+
 # ---------------------------------------------------------------------------
 # pipelines
 # ---------------------------------------------------------------------------

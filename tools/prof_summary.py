@@ -25,7 +25,7 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
             cnt[(k, row["Counter_Name"])] += 1
     print("== pmc:", os.path.basename(d))
     for k, cs in agg.items():
-        if "fir" in k or "demod" in k or "mfma" in k:
+        if "fir" in k or "demod" in k or "mfma" in k or "fused" in k:
             print("  ", k)
             for c, v in cs.items():
                 n = cnt[(k, c)]
