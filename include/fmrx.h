@@ -221,7 +221,8 @@ FMRX_API int fmrx_pipeline_last_timing(fmrx_pipeline *pl, float *t);
 /* sums of the same four figures over the most recent profiled calls (at most
  * max_calls, at most the 128 the handle keeps); *count = calls summed */
 FMRX_API int fmrx_pipeline_timing_sum(fmrx_pipeline *pl, float *t, int *count, int max_calls);
-/* enable (1) / disable (0) the per-stage HIP events behind last_timing */
+/* per-stage HIP events behind last_timing / timing_sum: 0 = off, 1 = around every process call,
+ * k > 1 = around every k-th call (an event record costs a few microseconds of stream time) */
 FMRX_API int fmrx_pipeline_set_profiling(fmrx_pipeline *pl, int on);
 /* The fused front end consumes the IF I/Q samples in registers and does not
  * write them to memory.  on = 1 makes it also store them so that

@@ -309,7 +309,7 @@ void build_image(const float *h, int s, std::vector<int8_t> &img)
 // such groups, K = the TA-1+15*DA+1 discriminator samples a column touches, A = the audio taps,
 // Toeplitz-shifted per row, resident in VGPRs.  A run that does not start the block first computes
 // the tile in front of it for the TA-1 samples of audio history ("dry": nothing stored).
-template <int T, int D, int TA, int DA>
+template <int T, int D, int TA, int DA, int PF = 0, int DRF = 0>
 struct FuCfg {
     using F = MfCfg<T, D>;
     static constexpr int TILE_OUT = 128;
@@ -317,7 +317,7 @@ struct FuCfg {
     static constexpr int NPF = TILE_BYTES / 1024;
     static constexpr int REM_LANES = (TILE_BYTES % 1024) / 16;
     static constexpr int NP = NPF + (REM_LANES ? 1 : 0);
-    static constexpr int P = iclamp(6144 / TILE_BYTES, 2, 8);      // tiles in flight beyond the one being multiplied
+    static constexpr int P = PF ? PF : iclamp(6144 / TILE_BYTES, 2, 8);   // tiles in flight beyond the one being multiplied
     static constexpr int NSLOT = P + 1;
     static constexpr int RING = NSLOT * TILE_BYTES;                // byte ring: slot t holds bytes [t*TILE - FRONT, (t+1)*TILE - FRONT)
     static constexpr int PIECE0 = NPF ? 1024 : TILE_BYTES;
@@ -331,10 +331,21 @@ struct FuCfg {
     static_assert(TB * TILE_OUT == AB_OUT * DA, "batches end on tile boundaries");
     static constexpr int AWIN = (TA - 1) + 15 * DA + 1;            // discriminator samples a column's 16 outputs touch
     static constexpr int AK = (AWIN + 3) / 4;                      // K-steps of the 16x16x4 MFMA
-    static constexpr int DR = 2048;                                // discriminator ring, floats
-    static_assert(AB_OUT * DA + TA - 1 + 4 * AK - AWIN <= DR, "a batch's window must fit the ring");
+    // A finished batch is multiplied in NPH slices of KPT K-steps, one slice per following tile, so
+    // that no wave ever stops streaming for a whole batch (all waves would at the same time).  Its
+    // window must survive the NPH tiles that are written meanwhile:
+    static constexpr int KPT = (AK + TB - 3) / (TB - 2);           // K-steps per slice
+    static constexpr int NPH = (AK + KPT - 1) / KPT;               // slices per batch, <= TB - 2
+    static constexpr int DR = DRF ? DRF : 3072;                    // discriminator ring, floats (a multiple of TILE_OUT)
+    static_assert(NPH <= TB - 2, "a batch must be done before the next one completes");
+    static_assert(AB_OUT * DA + TA - 1 + (4 * AK - AWIN) + (NPH + 1) * TILE_OUT <= DR, "ring too small for the delayed multiply");
+    static_assert(DR % TILE_OUT == 0, "tiles must not wrap inside");
     static_assert(TA - 1 <= TILE_OUT - 1, "one dry tile must cover the audio history");
-    static constexpr int LDS_WAVE = RING + DR * 4;
+    // the ring's first MIRROR samples are kept a second time behind its end, so that the KPT reads of
+    // a slice are one base address + immediate offsets (no wrap inside a slice)
+    static constexpr int MIRROR = 4 * KPT;
+    static_assert(MIRROR <= TILE_OUT, "the mirror is refreshed by the tile at position 0");
+    static constexpr int LDS_WAVE = RING + (DR + MIRROR) * 4;
 };
 
 template <class C, class F>
@@ -363,7 +374,7 @@ __device__ __forceinline__ void fu_dma_slot(const uint8_t *__restrict__ x, const
     }
 }
 
-template <int T, int D, int TA, int DA>
+template <int T, int D, int TA, int DA, int PF = 0, int DRF = 0, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
     const uint8_t *__restrict__ x, const uint8_t *__restrict__ hist_end, long n_bytes, const i4 *__restrict__ a_img,
     float scale_lo, const float *__restrict__ au_img, const float2 *__restrict__ prev_in,
@@ -371,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
     float *__restrict__ audio, int16_t *__restrict__ pcm, int wrap, long n_out, int n_tiles, long n_audio, int n_batches,
     int batches_per_wave, uint8_t *__restrict__ hist_next, int hist_bytes)
 {
-    using C = FuCfg<T, D, TA, DA>;
+    using C = FuCfg<T, D, TA, DA, PF, DRF>;
     using F = typename C::F;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const int lane = threadIdx.x & 63;
@@ -400,14 +411,16 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
 #pragma unroll
     for (int j = 0; j < C::AK; j++) au[j] = au_img[j * 64 + lane];
     float ci = 0.0f, cq = 0.0f;
-    // the ring starts finite everywhere: padding taps are zeros, and 0 * (stale NaN bits) is not 0
-    for (int i = lane; i < C::DR; i += 64) dring[i] = 0.0f;
+    // Ring position of discriminator sample i: (i - (128*tb - 128)) mod DR, so a tile never wraps
+    // inside and the history in front of the run has positive positions.
+    // The ring starts finite everywhere: padding taps are zeros, and 0 * (stale NaN bits) is not 0.
+    for (int i = lane; i < C::DR + C::MIRROR; i += 64) dring[i] = 0.0f;
     if (t0 == 0) {
         const float2 p = *prev_in;                            // prev_i/prev_q (src/project.cpp:122-126)
         ci = p.x;
         cq = p.y;
         // state_mono (src/project.cpp:346): the previous block's last TA-1 discriminator samples
-        for (int i = lane; i < TA - 1; i += 64) dring[(i - (TA - 1)) & (C::DR - 1)] = dhist_end[i - (TA - 1)];
+        for (int i = lane; i < TA - 1; i += 64) dring[C::TILE_OUT - (TA - 1) + i] = dhist_end[i - (TA - 1)];
     }
     // everything an ordinary load returns is in registers / LDS before the first DMA is issued (the
     // compiler drains vmcnt to 0 at the use of a plain load: keep that out of the streaming loop)
@@ -432,87 +445,46 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
     const int lane_off = F::COL_BYTES * col + 16 * g;
     const float scale_hi = scale_lo * 65536.0f;
     const int src_lane = lane >= 16 ? lane - 16 : lane + 47;   // who holds the output in front of this lane's first
+    int wrap_adr[F::KSTEPS];                                   // B fragment addresses of the ring's last slot (its window wraps)
+#pragma unroll
+    for (int j = 0; j < F::KSTEPS; j++) {
+        const int adr = (C::NSLOT - 1) * C::TILE_BYTES + lane_off + 64 * j;
+        wrap_adr[j] = adr >= C::RING ? adr - C::RING : adr;
+    }
     int slot = 0;
-    for (int t = tb; t < t1; t++) {
-        // tile t's slot and the first piece of slot t+1 have landed (vmcnt counts in issue order; the
-        // occasional output stores are not credited, which only waits longer)
-        if (t + C::P <= t1) wait_vmcnt<C::YOUNGER>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-
-        const int base = slot * C::TILE_BYTES + lane_off;
-        i4 b[F::KSTEPS];
+    int dpos = C::TILE_OUT;                                    // ring position of tile t's first sample (wave-uniform)
+    // the batch being multiplied (at most one): its accumulators, next slice, window, outputs
+    bool pend = false;
+    int pend_ph = 0, pend_ws = 0;
+    long pend_a0 = 0;
+    f4 y0 = (f4){0.0f, 0.0f, 0.0f, 0.0f}, y1 = y0;
+    // ---- audio FIR: the pending batch is multiplied one slice of KPT K-steps per tile, its LDS reads
+    //      issued with the tile's own and its MFMAs behind the tile's, so they hide behind the front
+    //      end's epilogue --------------------------------------------------------------------------------
+    float xs[C::KPT];
+    auto slice_load = [&]() {
+        // pend_ws walks the window, 4 samples per K-step; one wrap per slice thanks to the mirror
 #pragma unroll
-        for (int j = 0; j < F::KSTEPS; j++) {
-            int adr = base + 64 * j;
-            adr = adr >= C::RING ? adr - C::RING : adr;
-            b[j] = *reinterpret_cast<const i4 *>(ring + adr);
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0): the slot may be refilled
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (t + C::P + 1 <= t1) fu_dma_slot<C, F>(x, hist_end, n_bytes, t + C::P + 1, ring, slot, lane);
-
-        i4 acc[F::NDIG];
+        for (int k = 0; k < C::KPT; k++) xs[k] = dring[pend_ws + 4 * k];   // < DR + MIRROR; past AK: read, not used
+        pend_ws += 4 * C::KPT;
+        pend_ws = pend_ws >= C::DR ? pend_ws - C::DR : pend_ws;
+    };
+    auto slice_mfma = [&]() {
 #pragma unroll
-        for (int d = 0; d < F::NDIG; d++) acc[d] = (i4){0, 0, 0, 0};
+        for (int ph = 0; ph < C::NPH; ph++)
+            if (pend_ph == ph) {
 #pragma unroll
-        for (int j = 0; j < F::KSTEPS; j++) {
-            const i4 bs = b[j] ^ static_cast<int>(0x80808080u);   // u8 ^ 0x80 = (u8 - 128) as int8
-#pragma unroll
-            for (int d = 0; d < F::NDIG; d++) acc[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[j][d], bs, acc[d], 0, 0, 0);
-        }
-        float v[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            int lo = acc[0][k];
-            if (F::NDIG >= 2) lo += acc[1][k] * 256;
-            const float flo = static_cast<float>(lo) * scale_lo;
-            v[k] = F::NDIG >= 3 ? __builtin_fmaf(static_cast<float>(acc[2][k]), scale_hi, flo) : flo;
-        }
-        float pi = __shfl(v[2], src_lane, 64), pq = __shfl(v[3], src_lane, 64);
-        if (lane == 0) {
-            pi = ci;
-            pq = cq;
-        }
-        ci = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[2]), 63));
-        cq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[3]), 63));
-        const float d0 = demod_fast(v[0], v[1], pi, pq);
-        const float d1 = demod_fast(v[2], v[3], v[0], v[1]);
-
-        const long o = static_cast<long>(t) * C::TILE_OUT + F::COL_OUT * col + 2 * g;
-        *reinterpret_cast<f2 *>(dring + (static_cast<int>(o) & (C::DR - 1))) = (f2){d0, d1};
-        if (t >= t0 && o + 2 > n_out - tail_keep && o < n_out) {
-            // state_mono and prev_i/prev_q for the next block (the discriminator's last samples)
-            if (o >= n_out - tail_keep) demod_tail[o] = d0;
-            if (o + 1 < n_out) demod_tail[o + 1] = d1;
-            if (prev_out && o + 2 == n_out) *prev_out = make_float2(v[2], v[3]);
-            if (prev_out && o + 1 == n_out) *prev_out = make_float2(v[0], v[1]);
-        }
-        slot = slot + 1 == C::NSLOT ? 0 : slot + 1;
-
-        // ---- a batch of 256 audio outputs is complete (or the block ends) ----------------------
-        if (t >= t0 && ((t + 1) % C::TB == 0 || t + 1 == n_tiles)) {
-            const int bt = t / C::TB;
-            const long a0 = static_cast<long>(bt) * C::AB_OUT + 16 * col;           // first output of this lane's column
-            const int ws = static_cast<int>(a0 * DA - (TA - 1)) + g;                 // its window start (+ this lane's k)
-            f4 y0 = (f4){0.0f, 0.0f, 0.0f, 0.0f}, y1 = y0;
-            __builtin_amdgcn_s_waitcnt(0xC07F);                                      // the ring writes above
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int j0 = 0; j0 < C::AK; j0 += 8) {
-                float xs[8];
-#pragma unroll
-                for (int j = j0; j < j0 + 8 && j < C::AK; j++) xs[j - j0] = dring[(ws + 4 * j) & (C::DR - 1)];
-#pragma unroll
-                for (int j = j0; j < j0 + 8 && j < C::AK; j++) {
-                    if (j & 1) y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(au[j], xs[j - j0], y1, 0, 0, 0);
-                    else y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(au[j], xs[j - j0], y0, 0, 0, 0);
+                for (int j = ph * C::KPT; j < (ph + 1) * C::KPT && j < C::AK; j++) {
+                    if (j & 1) y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(au[j], xs[j - ph * C::KPT], y1, 0, 0, 0);
+                    else y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(au[j], xs[j - ph * C::KPT], y0, 0, 0, 0);
                 }
             }
+    };
+    auto slice_done = [&]() {
+        pend_ph++;
+        if (pend_ph == C::NPH) {
             const f4 y = y0 + y1;
-            const long ao = a0 + 4 * g;                                              // this lane's 4 consecutive outputs
+            const long ao = pend_a0 + 4 * g;                                         // this lane's 4 consecutive outputs
             if (ao + 3 < n_audio) {
                 if (audio) *reinterpret_cast<f4 *>(audio + ao) = y;
                 if (pcm) {
@@ -528,18 +500,112 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
                         if (pcm) pcm[ao + k] = pcm_pack(y[k], wrap);
                     }
             }
-            __builtin_amdgcn_s_waitcnt(0xC07F);                                      // ring reads done before it is written again
-            __builtin_amdgcn_wave_barrier();
+            pend = false;
         }
+    };
+    for (int t = tb;;) {
+        const bool have_tile = t < t1;
+        bool completed = false;
+        if (have_tile) {
+            const bool sl = pend;                                  // a slice of the pending batch rides along (wave-uniform)
+            // tile t's slot and the first piece of slot t+1 have landed (vmcnt counts in issue order; the
+            // occasional output stores are not credited, which only waits longer)
+            if (t + C::P <= t1) wait_vmcnt<C::YOUNGER>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+
+            i4 b[F::KSTEPS];
+            if (slot != C::NSLOT - 1) {                            // wave-uniform: the window cannot reach the ring's end
+                const uint8_t *bsrc = ring + slot * C::TILE_BYTES + lane_off;
+#pragma unroll
+                for (int j = 0; j < F::KSTEPS; j++) b[j] = *reinterpret_cast<const i4 *>(bsrc + 64 * j);
+            } else {
+#pragma unroll
+                for (int j = 0; j < F::KSTEPS; j++) b[j] = *reinterpret_cast<const i4 *>(ring + wrap_adr[j]);
+            }
+            if (sl) slice_load();
+            __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0): the slot may be refilled
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (t + C::P + 1 <= t1) fu_dma_slot<C, F>(x, hist_end, n_bytes, t + C::P + 1, ring, slot, lane);
+
+            i4 acc[F::NDIG];
+#pragma unroll
+            for (int d = 0; d < F::NDIG; d++) acc[d] = (i4){0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < F::KSTEPS; j++) {
+                const i4 bs = b[j] ^ static_cast<int>(0x80808080u);   // u8 ^ 0x80 = (u8 - 128) as int8
+#pragma unroll
+                for (int d = 0; d < F::NDIG; d++) acc[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[j][d], bs, acc[d], 0, 0, 0);
+            }
+            if (sl) slice_mfma();
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int lo = acc[0][k];
+                if (F::NDIG >= 2) lo += acc[1][k] * 256;
+                const float flo = static_cast<float>(lo) * scale_lo;
+                v[k] = F::NDIG >= 3 ? __builtin_fmaf(static_cast<float>(acc[2][k]), scale_hi, flo) : flo;
+            }
+            float pi = __shfl(v[2], src_lane, 64), pq = __shfl(v[3], src_lane, 64);
+            if (lane == 0) {
+                pi = ci;
+                pq = cq;
+            }
+            ci = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[2]), 63));
+            cq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[3]), 63));
+            const float d0 = demod_fast(v[0], v[1], pi, pq);
+            const float d1 = demod_fast(v[2], v[3], v[0], v[1]);
+
+            const int ol = F::COL_OUT * col + 2 * g;               // this lane's first output inside the tile
+            const long o = static_cast<long>(t) * C::TILE_OUT + ol;
+            *reinterpret_cast<f2 *>(dring + dpos + ol) = (f2){d0, d1};
+            if (dpos == 0 && ol < C::MIRROR) *reinterpret_cast<f2 *>(dring + C::DR + ol) = (f2){d0, d1};
+            if (t >= t0 && static_cast<long>(t + 1) * C::TILE_OUT > n_out - tail_keep &&   // wave-uniform: last tiles only
+                o + 2 > n_out - tail_keep && o < n_out) {
+                // state_mono and prev_i/prev_q for the next block (the discriminator's last samples)
+                if (o >= n_out - tail_keep) demod_tail[o] = d0;
+                if (o + 1 < n_out) demod_tail[o + 1] = d1;
+                if (prev_out && o + 2 == n_out) *prev_out = make_float2(v[2], v[3]);
+                if (prev_out && o + 1 == n_out) *prev_out = make_float2(v[0], v[1]);
+            }
+            slot = slot + 1 == C::NSLOT ? 0 : slot + 1;
+            dpos = dpos + C::TILE_OUT == C::DR ? 0 : dpos + C::TILE_OUT;
+            if (sl) slice_done();
+            completed = !(DBG & 1) && t >= t0 && ((t + 1) % C::TB == 0 || t + 1 == n_tiles);
+            t++;
+        }
+
+        // ---- all that is left of the pending batch when the next one is already complete or the run
+        //      is over ---------------------------------------------------------------------------------
+        while (pend && (completed || !have_tile)) {
+            slice_load();
+            slice_mfma();
+            slice_done();
+        }
+        if (completed) {
+            // batch bt = audio outputs [256 bt, 256 bt + 256) is in the ring: column `col` starts at
+            // discriminator sample DA*(256 bt + 16 col) - (TA-1); this lane reads K index g of every step
+            const int bt = (t - 1) / C::TB;
+            pend = true;
+            pend_ph = 0;
+            pend_a0 = static_cast<long>(bt) * C::AB_OUT + 16 * col;
+            int sb = (bt * C::AB_OUT * DA - (TA - 1)) - (C::TILE_OUT * tb - C::TILE_OUT);   // wave-uniform, >= 0
+            pend_ws = (sb + 16 * col * DA + g) % C::DR;
+            y0 = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+            y1 = y0;
+        }
+        if (!have_tile && !pend) break;
     }
 }
 
-template <int T, int D, int TA, int DA>
+template <int T, int D, int TA, int DA, int PF = 0, int DRF = 0, int DBG = 0>
 int launch_fused_mono(const FePlan &fe, const AudioPlan &au, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist,
                       const float *d_prev, const float *d_dhist_end, float *d_demod_tail, int tail_keep, float *d_prev_out,
                       float *d_audio, int16_t *d_pcm, int wrap, uint8_t *d_hist_next, hipStream_t stream)
 {
-    using C = FuCfg<T, D, TA, DA>;
+    using C = FuCfg<T, D, TA, DA, PF, DRF>;
     if (C::F::FRONT > fe.hist_bytes) return fail(FMRX_EINVAL, "mono_fused: history too short");
     const long n_out = static_cast<long>(n_samples / D);
     const long n_tiles = (n_out + C::TILE_OUT - 1) / C::TILE_OUT;
@@ -550,7 +616,15 @@ int launch_fused_mono(const FePlan &fe, const AudioPlan &au, const uint8_t *d_iq
     const long max_waves = 256 * wgs_per_cu * 4;
     const long bpw = (n_batches + max_waves - 1) / max_waves;
     const long grid = ((n_batches + bpw - 1) / bpw + 3) / 4;
-    hipLaunchKernelGGL((mono_fused_kernel<T, D, TA, DA>), dim3(static_cast<unsigned>(grid)), dim3(256), 4 * C::LDS_WAVE, stream,
+    if (4 * C::LDS_WAVE > 64 * 1024) {   // more dynamic LDS than the default cap: opt in once
+        static bool raised = false;
+        if (!raised) {
+            FMRX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mono_fused_kernel<T, D, TA, DA, PF, DRF, DBG>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 4 * C::LDS_WAVE));
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL((mono_fused_kernel<T, D, TA, DA, PF, DRF, DBG>), dim3(static_cast<unsigned>(grid)), dim3(256), 4 * C::LDS_WAVE, stream,
                        d_iq, d_hist + fe.hist_bytes, static_cast<long>(2 * n_samples), reinterpret_cast<const i4 *>(fe.a_img.p),
                        fe.scale_lo, au.mfma_table.p, reinterpret_cast<const float2 *>(d_prev), d_dhist_end, d_demod_tail,
                        tail_keep, reinterpret_cast<float2 *>(d_prev_out), d_audio, d_pcm, wrap, n_out, static_cast<int>(n_tiles),
@@ -664,6 +738,15 @@ int mono_fused_launch(const FePlan &fe, const AudioPlan &au, const uint8_t *d_iq
                       float *d_audio, int16_t *d_pcm, int wrap, uint8_t *d_hist_next, hipStream_t stream)
 {
     if (!d_prev || !d_dhist_end || !d_demod_tail) return fail(FMRX_EINVAL, "mono_fused_launch: null argument");
+    if (const char *e = std::getenv("FMRX_FUSED_TUNE")) {   // tuning variants, (101,10,101,5) only: <DBG><P>
+        const int v = std::atoi(e);
+#define Y(G_, P_)                                                                                                         \
+    if (fe.taps == 101 && fe.decim == 10 && au.taps == 101 && au.decim == 5 && v == G_ * 10 + P_)                          \
+        return launch_fused_mono<101, 10, 101, 5, P_, 0, G_>(fe, au, d_iq, n_samples, d_hist, d_prev, d_dhist_end, d_demod_tail, \
+                                                            tail_keep, d_prev_out, d_audio, d_pcm, wrap, d_hist_next, stream);
+        Y(0, 2) Y(1, 2)
+#undef Y
+    }
 #define X(T_, D_, TA_, DA_)                                                                                          \
     if (fe.taps == T_ && fe.decim == D_ && au.taps == TA_ && au.decim == DA_)                                         \
         return launch_fused_mono<T_, D_, TA_, DA_>(fe, au, d_iq, n_samples, d_hist, d_prev, d_dhist_end, d_demod_tail, \

@@ -31,6 +31,8 @@ struct fmrx_pipeline {
     bool resample = false;
     bool force_generic = false;
     bool profiling = false;
+    int prof_every = 1;           // HIP events around every prof_every-th call
+    unsigned long seq = 0;        // calls since profiling was enabled
     int Ha = 0;     // audio-stage history, in its input samples
     int delay = 0;  // all-pass delay (stereo), samples
     int Hd = 0;     // history kept in front of demod (>= what the stages need, multiple of 4: keeps demod[0] 16-byte aligned)
@@ -293,6 +295,8 @@ int fmrx_pipeline_set_profiling(fmrx_pipeline *pl, int on)
 {
     if (!pl) return fail(FMRX_EINVAL, "null handle");
     pl->profiling = on != 0;
+    pl->prof_every = on > 1 ? on : 1;
+    pl->seq = 0;
     pl->calls = 0;
     return FMRX_OK;
 }
@@ -350,8 +354,10 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
         return FMRX_OK;
     };
 
+    // events around every prof_every-th call: a record costs ~5 us of stream time
+    const bool prof = pl->profiling && (pl->seq++ % static_cast<unsigned long>(pl->prof_every) == 0);
     hipEvent_t *ev = pl->ev[pl->calls % fmrx_pipeline::kRing];
-    if (pl->profiling) FMRX_HIP(hipEventRecord(ev[0], s));
+    if (prof) FMRX_HIP(hipEventRecord(ev[0], s));
 
     // ---- RF_FrontEnd: project.cpp:82-128 (u8 -> IF I/Q -> discriminator) ----
     const uint8_t *hist = pl->fe_hist[pl->fe_cur].p;
@@ -376,13 +382,13 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
         pl->prev_cur ^= 1;
         pl->prev_override = false;
         pl->fe_cur ^= 1;
-        if (pl->profiling) FMRX_HIP(hipEventRecord(ev[1], s));
+        if (prof) FMRX_HIP(hipEventRecord(ev[1], s));
         if (!hist_done)
             hipLaunchKernelGGL(hist_update_kernel, dim3((hb + 255) / 256), dim3(256), 0, s, hist, d_iq,
                                static_cast<long>(n_bytes), hb, hist_next);
         pl->demod_last = cur;
         pl->demod_n_last = n_if;
-        if (pl->profiling) {
+        if (prof) {
             FMRX_HIP(hipEventRecord(ev[2], s));
             FMRX_HIP(hipEventRecord(ev[3], s));
             pl->calls++;
@@ -411,7 +417,7 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
     pl->prev_cur ^= 1;
     pl->prev_override = false;
     pl->fe_cur ^= 1;
-    if (pl->profiling) FMRX_HIP(hipEventRecord(ev[1], s));
+    if (prof) FMRX_HIP(hipEventRecord(ev[1], s));
     if (!hist_done)
         hipLaunchKernelGGL(hist_update_kernel, dim3((hb + 255) / 256), dim3(256), 0, s, hist, d_iq,
                            static_cast<long>(n_bytes), hb, hist_next);
@@ -430,7 +436,7 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
         FMRX_TRY(audio_fir_launch(pl->audio, demod, fast ? hist_end : nullptr, n_if, 0, dst, d_pcm16, pcm_policy, s,
                                   pl->force_generic));
         pl->last_mono = dst;
-        if (pl->profiling) {
+        if (prof) {
             FMRX_HIP(hipEventRecord(ev[2], s));
             FMRX_HIP(hipEventRecord(ev[3], s));
             pl->calls++;
@@ -444,12 +450,12 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
     if (pl->channels == 1) {
         // ---- RF_MONO, modes 2/3: rational resampler (project.cpp:353) ----
         FMRX_TRY(audio_stage(pl, demod, n_if, 0, pl->mono.p, s));
-        if (pl->profiling) FMRX_HIP(hipEventRecord(ev[2], s));
+        if (prof) FMRX_HIP(hipEventRecord(ev[2], s));
     } else {
         // ---- RF_STEREO: project.cpp:194-280 ----
         float *mixer = pl->mixer.p + pl->Hm;
         FMRX_TRY(audio_stage(pl, demod, n_if, pl->delay, pl->mono.p, s));  // all-pass = index offset
-        if (pl->profiling) FMRX_HIP(hipEventRecord(ev[2], s));
+        if (prof) FMRX_HIP(hipEventRecord(ev[2], s));
         FMRX_TRY(bpf_pair_launch(pl->bpf_plan, demod, n_if, pl->bpf.p, pl->carrier.p, s, pl->force_generic));
         if (pl->force_generic)
             FMRX_TRY(k_fm_pll(pl->carrier.p, n_if, pl->pll.p, pl->pll_state.p, 19e3f, static_cast<float>(p.if_Fs), 2.0f,
@@ -485,7 +491,7 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
         if (out_r) FMRX_TRY(k_pcm16_stereo(out_l, out_r, n_au, d_pcm16, pcm_policy, s));
         else FMRX_TRY(k_pcm16(out_l, n_au, d_pcm16, pcm_policy, s));
     }
-    if (pl->profiling) {
+    if (prof) {
         FMRX_HIP(hipEventRecord(ev[3], s));
         pl->calls++;
     }

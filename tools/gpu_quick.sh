@@ -10,7 +10,7 @@ if [ $rc -ge 124 ]; then exit $rc; fi
 python3 - <<'PY'
 import json
 d=json.loads([l for l in open('gpurun_out/bench.log') if l.startswith('{')][-1])
-r=d['roofline']; print('value',d['value'],'ms/step',d['ms_per_step'],'fe_ms',r['avg_launch_ms'],'frac',r['frac'],'tflops',r['fp32_tflops'],'stages',r['stage_ms'])
+r=d['roofline']; print('value',d['value'],'ms/step',d['ms_per_step'],'fe_ms',r['avg_launch_ms'],'frac',r['frac'],'stages',r['stage_ms'])
 PY
 export TMPDIR=/tmp
 mkdir -p gpurun_out/prof; rm -rf gpurun_out/prof/pmc_q; timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d gpurun_out/prof/pmc_q -o pmc_q -- python3 tools/prof_target.py 3 256 > gpurun_out/prof/pmc_q.log 2>&1
