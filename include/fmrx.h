@@ -224,9 +224,12 @@ FMRX_API int fmrx_pipeline_timing_sum(fmrx_pipeline *pl, float *t, int *count, i
 /* per-stage HIP events behind last_timing / timing_sum: 0 = off, 1 = around every process call,
  * k > 1 = around every k-th call (an event record costs a few microseconds of stream time) */
 FMRX_API int fmrx_pipeline_set_profiling(fmrx_pipeline *pl, int on);
-/* The fused front end consumes the IF I/Q samples in registers and does not
- * write them to memory.  on = 1 makes it also store them so that
- * FMRX_TAP_IF_I / FMRX_TAP_IF_Q can be read (diagnostics; default 0). */
+/* The front-end kernels consume the IF I/Q samples in registers, and the fused
+ * mono kernel (modes 0/1, one channel, large blocks) the discriminator output
+ * too: neither is written to memory.  on = 1 selects the kernels that store
+ * them, so that FMRX_TAP_IF_I / FMRX_TAP_IF_Q / FMRX_TAP_DEMOD can be read
+ * after a process call (diagnostics and tests; default 0; read_tap returns
+ * FMRX_EINVAL for a tap that was not stored). */
 FMRX_API int fmrx_pipeline_set_keep_intermediates(fmrx_pipeline *pl, int on);
 /* Stereo only.  The pilot PLL (fmPLL, src/filter.cpp:32-80) runs parallel in time
  * (segments with warm-up, verified against the neighbouring segment, serial repair

@@ -309,7 +309,7 @@ void build_image(const float *h, int s, std::vector<int8_t> &img)
 // such groups, K = the TA-1+15*DA+1 discriminator samples a column touches, A = the audio taps,
 // Toeplitz-shifted per row, resident in VGPRs.  A run that does not start the block first computes
 // the tile in front of it for the TA-1 samples of audio history ("dry": nothing stored).
-template <int T, int D, int TA, int DA, int PF = 0, int DRF = 0>
+template <int T, int D, int TA, int DA, int PF = 0, int DRF = 0, int KPTF = 0>
 struct FuCfg {
     using F = MfCfg<T, D>;
     static constexpr int TILE_OUT = 128;
@@ -330,11 +330,13 @@ struct FuCfg {
     static constexpr int TB = AB_OUT * DA / TILE_OUT;              // tiles per batch
     static_assert(TB * TILE_OUT == AB_OUT * DA, "batches end on tile boundaries");
     static constexpr int AWIN = (TA - 1) + 15 * DA + 1;            // discriminator samples a column's 16 outputs touch
-    static constexpr int AK = (AWIN + 3) / 4;                      // K-steps of the 16x16x4 MFMA
+    static constexpr int AK = (AWIN + 15) / 16 * 4;                // K-steps of the 16x16x4 MFMA, in whole groups of 4
     // A finished batch is multiplied in NPH slices of KPT K-steps, one slice per following tile, so
     // that no wave ever stops streaming for a whole batch (all waves would at the same time).  Its
     // window must survive the NPH tiles that are written meanwhile:
-    static constexpr int KPT = (AK + TB - 3) / (TB - 2);           // K-steps per slice
+    static_assert(AK % 4 == 0 && (TA - 1) % 4 == 0, "window in whole 16-byte groups");
+    // K-steps per slice: whole groups of 4 (one ds_read_b128 per lane feeds 4 K-steps, see slice_load)
+    static constexpr int KPT = KPTF ? KPTF : ((AK + TB - 3) / (TB - 2) + 3) / 4 * 4;
     static constexpr int NPH = (AK + KPT - 1) / KPT;               // slices per batch, <= TB - 2
     static constexpr int DR = DRF ? DRF : 3072;                    // discriminator ring, floats (a multiple of TILE_OUT)
     static_assert(NPH <= TB - 2, "a batch must be done before the next one completes");
@@ -374,7 +376,7 @@ __device__ __forceinline__ void fu_dma_slot(const uint8_t *__restrict__ x, const
     }
 }
 
-template <int T, int D, int TA, int DA, int PF = 0, int DRF = 0, int DBG = 0>
+template <int T, int D, int TA, int DA, int PF = 0, int DRF = 0, int DBG = 0, int KPTF = 0>
 __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
     const uint8_t *__restrict__ x, const uint8_t *__restrict__ hist_end, long n_bytes, const i4 *__restrict__ a_img,
     float scale_lo, const float *__restrict__ au_img, const float2 *__restrict__ prev_in,
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
     float *__restrict__ audio, int16_t *__restrict__ pcm, int wrap, long n_out, int n_tiles, long n_audio, int n_batches,
     int batches_per_wave, uint8_t *__restrict__ hist_next, int hist_bytes)
 {
-    using C = FuCfg<T, D, TA, DA, PF, DRF>;
+    using C = FuCfg<T, D, TA, DA, PF, DRF, KPTF>;
     using F = typename C::F;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const int lane = threadIdx.x & 63;
@@ -461,11 +463,14 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
     // ---- audio FIR: the pending batch is multiplied one slice of KPT K-steps per tile, its LDS reads
     //      issued with the tile's own and its MFMAs behind the tile's, so they hide behind the front
     //      end's epilogue --------------------------------------------------------------------------------
-    float xs[C::KPT];
+    // K-step j of a batch, K index kq (= this lane's g) <-> window sample 16*(j/4) + 4*kq + j%4: a lane's
+    // operands of 4 consecutive K-steps are 4 consecutive samples, one 16-byte LDS read (the tap image
+    // is laid out to match, audio_mfma_table_init).
+    f4 xs[C::KPT / 4];
     auto slice_load = [&]() {
-        // pend_ws walks the window, 4 samples per K-step; one wrap per slice thanks to the mirror
+        // pend_ws walks the window, 16 samples per group of K-steps; one wrap per slice thanks to the mirror
 #pragma unroll
-        for (int k = 0; k < C::KPT; k++) xs[k] = dring[pend_ws + 4 * k];   // < DR + MIRROR; past AK: read, not used
+        for (int k = 0; k < C::KPT / 4; k++) xs[k] = *reinterpret_cast<const f4 *>(dring + pend_ws + 16 * k);   // < DR + MIRROR
         pend_ws += 4 * C::KPT;
         pend_ws = pend_ws >= C::DR ? pend_ws - C::DR : pend_ws;
     };
@@ -475,8 +480,13 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
             if (pend_ph == ph) {
 #pragma unroll
                 for (int j = ph * C::KPT; j < (ph + 1) * C::KPT && j < C::AK; j++) {
-                    if (j & 1) y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(au[j], xs[j - ph * C::KPT], y1, 0, 0, 0);
-                    else y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(au[j], xs[j - ph * C::KPT], y0, 0, 0, 0);
+                    const float xv = xs[(j - ph * C::KPT) / 4][j % 4];
+                    if (DBG & 2) {
+                        y0[j & 3] += xv * au[j];
+                        continue;
+                    }
+                    if (j & 1) y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(au[j], xv, y1, 0, 0, 0);
+                    else y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(au[j], xv, y0, 0, 0, 0);
                 }
             }
     };
@@ -485,7 +495,8 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
         if (pend_ph == C::NPH) {
             const f4 y = y0 + y1;
             const long ao = pend_a0 + 4 * g;                                         // this lane's 4 consecutive outputs
-            if (ao + 3 < n_audio) {
+            if ((DBG & 8) && y[0] != 1234.5f) {
+            } else if (ao + 3 < n_audio) {
                 if (audio) *reinterpret_cast<f4 *>(audio + ao) = y;
                 if (pcm) {
                     using s4 = short __attribute__((ext_vector_type(4)));
@@ -535,7 +546,7 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
             for (int d = 0; d < F::NDIG; d++) acc[d] = (i4){0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < F::KSTEPS; j++) {
-                const i4 bs = b[j] ^ static_cast<int>(0x80808080u);   // u8 ^ 0x80 = (u8 - 128) as int8
+                const i4 bs = (DBG & 4) ? b[j] : b[j] ^ static_cast<int>(0x80808080u);   // u8 ^ 0x80 = (u8 - 128) as int8
 #pragma unroll
                 for (int d = 0; d < F::NDIG; d++) acc[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[j][d], bs, acc[d], 0, 0, 0);
             }
@@ -586,13 +597,13 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
         }
         if (completed) {
             // batch bt = audio outputs [256 bt, 256 bt + 256) is in the ring: column `col` starts at
-            // discriminator sample DA*(256 bt + 16 col) - (TA-1); this lane reads K index g of every step
+            // discriminator sample DA*(256 bt + 16 col) - (TA-1); this lane reads samples 4g..4g+3 of every 16
             const int bt = (t - 1) / C::TB;
             pend = true;
             pend_ph = 0;
             pend_a0 = static_cast<long>(bt) * C::AB_OUT + 16 * col;
             int sb = (bt * C::AB_OUT * DA - (TA - 1)) - (C::TILE_OUT * tb - C::TILE_OUT);   // wave-uniform, >= 0
-            pend_ws = (sb + 16 * col * DA + g) % C::DR;
+            pend_ws = (sb + 16 * col * DA + 4 * g) % C::DR;
             y0 = (f4){0.0f, 0.0f, 0.0f, 0.0f};
             y1 = y0;
         }
@@ -600,12 +611,12 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
     }
 }
 
-template <int T, int D, int TA, int DA, int PF = 0, int DRF = 0, int DBG = 0>
+template <int T, int D, int TA, int DA, int PF = 0, int DRF = 0, int DBG = 0, int KPTF = 0>
 int launch_fused_mono(const FePlan &fe, const AudioPlan &au, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist,
                       const float *d_prev, const float *d_dhist_end, float *d_demod_tail, int tail_keep, float *d_prev_out,
                       float *d_audio, int16_t *d_pcm, int wrap, uint8_t *d_hist_next, hipStream_t stream)
 {
-    using C = FuCfg<T, D, TA, DA, PF, DRF>;
+    using C = FuCfg<T, D, TA, DA, PF, DRF, KPTF>;
     if (C::F::FRONT > fe.hist_bytes) return fail(FMRX_EINVAL, "mono_fused: history too short");
     const long n_out = static_cast<long>(n_samples / D);
     const long n_tiles = (n_out + C::TILE_OUT - 1) / C::TILE_OUT;
@@ -619,12 +630,12 @@ int launch_fused_mono(const FePlan &fe, const AudioPlan &au, const uint8_t *d_iq
     if (4 * C::LDS_WAVE > 64 * 1024) {   // more dynamic LDS than the default cap: opt in once
         static bool raised = false;
         if (!raised) {
-            FMRX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mono_fused_kernel<T, D, TA, DA, PF, DRF, DBG>),
+            FMRX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mono_fused_kernel<T, D, TA, DA, PF, DRF, DBG, KPTF>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 4 * C::LDS_WAVE));
             raised = true;
         }
     }
-    hipLaunchKernelGGL((mono_fused_kernel<T, D, TA, DA, PF, DRF, DBG>), dim3(static_cast<unsigned>(grid)), dim3(256), 4 * C::LDS_WAVE, stream,
+    hipLaunchKernelGGL((mono_fused_kernel<T, D, TA, DA, PF, DRF, DBG, KPTF>), dim3(static_cast<unsigned>(grid)), dim3(256), 4 * C::LDS_WAVE, stream,
                        d_iq, d_hist + fe.hist_bytes, static_cast<long>(2 * n_samples), reinterpret_cast<const i4 *>(fe.a_img.p),
                        fe.scale_lo, au.mfma_table.p, reinterpret_cast<const float2 *>(d_prev), d_dhist_end, d_demod_tail,
                        tail_keep, reinterpret_cast<float2 *>(d_prev_out), d_audio, d_pcm, wrap, n_out, static_cast<int>(n_tiles),
@@ -706,14 +717,16 @@ int fe_mfma_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, cons
 
 // Toeplitz image of the audio taps in A-operand order of v_mfma_f32_16x16x4_f32: [kstep][lane], lane
 // (row i = lane&15, k = lane>>4) holds the tap that output i of a column applies to window sample
-// 4*kstep + k, i.e. h[decim*i + taps-1 - (4*kstep + k)], or 0 outside the filter.
+// w = 16*(kstep/4) + 4*k + kstep%4 (so that a lane's B operands of 4 consecutive K-steps are 4
+// consecutive samples), i.e. h[decim*i + taps-1 - w], or 0 outside the filter.
 int audio_mfma_table_init(AudioPlan &pl, const float *h, int taps, int decim)
 {
-    const int awin = (taps - 1) + 15 * decim + 1, ak = (awin + 3) / 4;
+    const int awin = (taps - 1) + 15 * decim + 1, ak = (awin + 15) / 16 * 4;
     std::vector<float> tab(static_cast<size_t>(ak) * 64, 0.0f);
     for (int j = 0; j < ak; j++)
         for (int lane = 0; lane < 64; lane++) {
-            const int k = decim * (lane & 15) + taps - 1 - (4 * j + (lane >> 4));
+            const int w = 16 * (j / 4) + 4 * (lane >> 4) + j % 4;   // window sample of (K-step j, K index lane>>4)
+            const int k = decim * (lane & 15) + taps - 1 - w;
             if (k >= 0 && k < taps) tab[j * 64 + lane] = h[k];
         }
     FMRX_TRY(pl.mfma_table.alloc(tab.size()));
@@ -738,13 +751,14 @@ int mono_fused_launch(const FePlan &fe, const AudioPlan &au, const uint8_t *d_iq
                       float *d_audio, int16_t *d_pcm, int wrap, uint8_t *d_hist_next, hipStream_t stream)
 {
     if (!d_prev || !d_dhist_end || !d_demod_tail) return fail(FMRX_EINVAL, "mono_fused_launch: null argument");
-    if (const char *e = std::getenv("FMRX_FUSED_TUNE")) {   // tuning variants, (101,10,101,5) only: <DBG><P>
+    if (const char *e = std::getenv("FMRX_FUSED_TUNE")) {   // tuning variants, (101,10,101,5) only
         const int v = std::atoi(e);
-#define Y(G_, P_)                                                                                                         \
-    if (fe.taps == 101 && fe.decim == 10 && au.taps == 101 && au.decim == 5 && v == G_ * 10 + P_)                          \
-        return launch_fused_mono<101, 10, 101, 5, P_, 0, G_>(fe, au, d_iq, n_samples, d_hist, d_prev, d_dhist_end, d_demod_tail, \
-                                                            tail_keep, d_prev_out, d_audio, d_pcm, wrap, d_hist_next, stream);
-        Y(0, 2) Y(1, 2)
+#define Y(ID_, P_, DR_, G_, K_)                                                                                            \
+    if (fe.taps == 101 && fe.decim == 10 && au.taps == 101 && au.decim == 5 && v == ID_)                                    \
+        return launch_fused_mono<101, 10, 101, 5, P_, DR_, G_, K_>(fe, au, d_iq, n_samples, d_hist, d_prev, d_dhist_end,    \
+                                                                  d_demod_tail, tail_keep, d_prev_out, d_audio, d_pcm, wrap, \
+                                                                  d_hist_next, stream);
+        Y(2, 2, 0, 0, 0) Y(12, 2, 0, 1, 0) Y(3, 2, 2304, 0, 8) Y(4, 3, 2304, 0, 8) Y(82, 2, 0, 8, 0) Y(102, 2, 0, 10, 0)
 #undef Y
     }
 #define X(T_, D_, TA_, DA_)                                                                                          \

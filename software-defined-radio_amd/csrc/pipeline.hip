@@ -133,6 +133,9 @@ int audio_stage(fmrx_pipeline *pl, const float *d_x, size_t n_in, int delay, flo
 
 int reset_state(fmrx_pipeline *pl)
 {
+    // process_dev runs on the caller's stream: whatever is still in flight there must not see the
+    // state change under it (reset is rare; a device-wide wait is the simple, safe order)
+    FMRX_HIP(hipDeviceSynchronize());
     hipStream_t s = pl->stream;
     for (int i = 0; i < 2; i++) {
         FMRX_TRY(k_fill_u8(pl->fe_hist[i].p, pl->fe.hist_bytes, 128, s));

@@ -14,6 +14,7 @@ step() {  # name, timeout, command...
 }
 step smoke 200 python -c "import __graft_entry__ as g; g.smoke()"
 step pytest_gpu 400 python -m pytest tests -m gpu -q --timeout 120 -rA
-step fe_ab 200 python tools/fe_ab.py 256 5
-step bench 300 python bench.py --steps 20 --warmup 3
-tail -3 gpurun_out/smoke.log; grep -E "passed|failed|FAILED|ERROR" gpurun_out/pytest_gpu.log | tail -15; cat gpurun_out/fe_ab.log; tail -3 gpurun_out/bench.log
+step bench 300 python bench.py
+step mode_bench 400 python tools/mode_bench.py 63 12
+step cli_bench 300 python tools/cli_bench.py
+tail -3 gpurun_out/smoke.log; grep -E "passed|failed|FAILED|ERROR" gpurun_out/pytest_gpu.log | tail -15; tail -1 gpurun_out/bench.log; tail -30 gpurun_out/mode_bench.log; tail -12 gpurun_out/cli_bench.log
