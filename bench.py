@@ -11,8 +11,10 @@ pack, synthetic 2.4 MS/s FM I/Q, blocks of 1,024,000 complex samples.  One
 "step" = one pass of the whole chain over a device-resident batch of
 `--blocks` (default 256) consecutive blocks of one stream (0.5 GB of u8 I/Q),
 submitted as one block-parallel call (the mono chain is a sliding-window map of
-its input, SURVEY A.4, so this equals block-by-block streaming bit for bit --
-tests/test_gpu_parity.py::test_block_split_invariance_on_device).  Inputs are
+its input, SURVEY A.4, so this equals block-by-block streaming: bit for bit in the
+IF / discriminator stages and the carried state, to float32 summation order
+(<= 2e-6) in the audio FIR of the fused kernel --
+tests/test_gpu_parity.py::test_fused_mono_kernel, ::test_block_split_invariance_on_device).  Inputs are
 resident in HBM when the timed region starts; outputs (f32 audio + s16 PCM) are
 written to HBM.  N>1: one process per GPU, one independent channel per GPU
 (seed + rank), no data-path collective (RCCL is used only for the barrier and

@@ -627,12 +627,14 @@ int launch_fused_mono(const FePlan &fe, const AudioPlan &au, const uint8_t *d_iq
     const long max_waves = 256 * wgs_per_cu * 4;
     const long bpw = (n_batches + max_waves - 1) / max_waves;
     const long grid = ((n_batches + bpw - 1) / bpw + 3) / 4;
-    if (4 * C::LDS_WAVE > 64 * 1024) {   // more dynamic LDS than the default cap: opt in once
-        static bool raised = false;
-        if (!raised) {
+    if (4 * C::LDS_WAVE > 64 * 1024) {   // more dynamic LDS than the default cap: opt in, once per device
+        static bool raised[64] = {};
+        int dev = 0;
+        FMRX_HIP(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64 || !raised[dev]) {
             FMRX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mono_fused_kernel<T, D, TA, DA, PF, DRF, DBG, KPTF>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 4 * C::LDS_WAVE));
-            raised = true;
+            if (dev >= 0 && dev < 64) raised[dev] = true;
         }
     }
     hipLaunchKernelGGL((mono_fused_kernel<T, D, TA, DA, PF, DRF, DBG, KPTF>), dim3(static_cast<unsigned>(grid)), dim3(256), 4 * C::LDS_WAVE, stream,
