@@ -135,6 +135,9 @@ struct ResamplePlan {
     int J = 0, JP = 0;         // taps per polyphase row, padded row length
     int span = 0;              // input samples one 256-output tile stages in LDS
     bool fast = false;
+    // LDS-resident table kernel: the taps are applied in npass passes of W taps (all phases x W taps
+    // fit LDS); tiles of 1024 outputs stage span_l inputs
+    int npass = 0, W = 0, span_l = 0;
     DevBuf<float> table;       // polyphase-major taps [upsamp][JP]
     DevBuf<float> h;           // plain taps (generic path)
 };

@@ -16,6 +16,13 @@
 //
 // Arithmetic is the reference's, operation for operation: products and sums
 // separately rounded, j ascending, then y += y*U -- the stage stays bit-exact.
+//
+// resample_lds_kernel goes one step further: 256 consecutive outputs hit every one of the U rows,
+// so the kernel above pulls ~100 KB of taps per workgroup from L2 and runs at L2 bandwidth.  The
+// whole table (59 KB) or half of it (mode 3: 2 x 92 KB) fits LDS: persistent workgroups of 1024
+// threads load their slice of W taps x all phases once and stream tiles of 1024 outputs past it.
+// A second pass continues every output's sum from where the first left it (the partial sum goes
+// through y as a float, so the rounding sequence -- j ascending -- is unchanged: still bit-exact).
 #include "fmrx_internal.hpp"
 
 #pragma clang fp contract(off)
@@ -63,6 +70,84 @@ __global__ __launch_bounds__(kNT) void resample_poly_kernel(const float *__restr
     y[k] = acc + g;
 }
 
+constexpr int kLT = 1024;   // threads = outputs per tile of the LDS-table kernel
+constexpr int kRowPad = 4;   // floats: rows then start on all 16 bank groups, not 8
+
+__global__ __launch_bounds__(kLT) void resample_lds_kernel(const float *__restrict__ x, long n_in, long n_out,
+                                                            const float *__restrict__ table, int J, int JP, int decim,
+                                                            int upsamp, int span, int j0, int W, int first, int last,
+                                                            long n_tiles, float *__restrict__ y)
+{
+    extern __shared__ float lds[];
+    const int WP = W + kRowPad;
+    float *tab = lds;                       // [upsamp][WP]: taps j0 .. j0+W-1 of every phase
+    float *xs = lds + upsamp * WP;          // [span]
+    const int t = threadIdx.x;
+    const int w4 = W / 4;
+    for (int i = t; i < upsamp * w4; i += kLT) {
+        const int row = i / w4, c = i - row * w4;
+        f4 v = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+        if (j0 + 4 * c < JP) v = *reinterpret_cast<const f4 *>(table + static_cast<long>(row) * JP + j0 + 4 * c);
+        *reinterpret_cast<f4 *>(tab + row * WP + 4 * c) = v;
+    }
+    // the next tile's inputs are fetched into registers while this tile is multiplied (one workgroup
+    // per CU: nothing else would hide the fetch)
+    constexpr int kNL = 8;                              // >= span / kLT (host checks)
+    float xn[kNL];
+    auto fetch = [&](long tile) {
+        const long lo = (tile * kLT * decim) / upsamp - (J - 1);   // oldest input any output of the tile touches
+#pragma unroll
+        for (int q = 0; q < kNL; q++) {
+            const int i = t + q * kLT;
+            const long g = lo + i;                      // negative -> carried history in front of the block
+            xn[q] = (i < span && g < n_in) ? x[g] : 0.0f;
+        }
+    };
+    if (static_cast<long>(blockIdx.x) < n_tiles) fetch(blockIdx.x);
+    for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const long k0 = tile * kLT;
+        const long lo = (k0 * decim) / upsamp - (J - 1);
+        __syncthreads();                                // the previous tile's reads of xs (and the table fill)
+#pragma unroll
+        for (int q = 0; q < kNL; q++)
+            if (t + q * kLT < span) xs[t + q * kLT] = xn[q];
+        __syncthreads();
+        if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
+        const long k = k0 + t;
+        if (k >= n_out) continue;
+        const long m = k * decim;
+        const int ph = static_cast<int>(m % upsamp);
+        const int b = static_cast<int>(m / upsamp - lo) - j0;   // index in xs of the sample tap j0 meets
+        const f4 *row = reinterpret_cast<const f4 *>(tab + ph * WP);
+        float acc = first ? 0.0f : y[k];
+        const int nfull = (J - j0) / 4 < w4 ? (J - j0) / 4 : w4;   // groups of 4 taps that exist entirely
+        const float *xp = xs + b;
+        for (int j4 = 0; j4 < nfull; j4++) {
+            const f4 h = row[j4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float prod = h[e] * xp[-(4 * j4 + e)];
+                acc = acc + prod;
+            }
+        }
+        if (nfull < w4) {                                          // the group the filter ends in
+            const f4 h = row[nfull];
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (j0 + 4 * nfull + e < J) {
+                    const float prod = h[e] * xp[-(4 * nfull + e)];
+                    acc = acc + prod;
+                }
+        }
+        if (last) {
+            const float g = acc * static_cast<float>(upsamp);
+            y[k] = acc + g;
+        } else {
+            y[k] = acc;
+        }
+    }
+}
+
 }  // namespace
 
 int resample_plan_init(ResamplePlan &pl, const float *h, int taps, int decim, int upsamp)
@@ -82,6 +167,18 @@ int resample_plan_init(ResamplePlan &pl, const float *h, int taps, int decim, in
     // inputs spanned by 256 consecutive outputs, plus the J-1 older ones
     pl.span = static_cast<int>((static_cast<long>(kNT) * decim + upsamp - 1) / upsamp) + pl.J + 1;
     pl.fast = pl.span * sizeof(float) <= 60 * 1024;
+    // LDS-table kernel: as few passes as make (all phases x W taps) + one tile's inputs fit 144 KB of LDS
+    pl.span_l = static_cast<int>((static_cast<long>(kLT) * decim + upsamp - 1) / upsamp) + pl.J + 1;
+    pl.npass = 0;
+    for (int np = 1; np <= 4; np++) {
+        const int W = (pl.JP / 4 + np - 1) / np * 4;
+        if (pl.span_l <= 8 * kLT &&   // the kernel prefetches a tile's inputs in 8 registers per thread
+            (static_cast<long>(upsamp) * (W + kRowPad) + pl.span_l) * sizeof(float) <= 144 * 1024) {
+            pl.npass = np;
+            pl.W = W;
+            break;
+        }
+    }
     return FMRX_OK;
 }
 
@@ -93,6 +190,29 @@ int resample_launch(const ResamplePlan &pl, const float *d_x, size_t n_in, int d
     if (n_out == 0) return FMRX_OK;
     if (!pl.fast || force_generic)
         return k_resample_generic(d_x - delay, n_in, pl.h.p, pl.taps, pl.decim, pl.upsamp, d_y, stream);
+    if (pl.npass > 0 && n_out >= 64 * kLT && std::getenv("FMRX_RESAMPLE_L2") == nullptr) {
+        const size_t lds_bytes = (static_cast<size_t>(pl.upsamp) * (pl.W + kRowPad) + pl.span_l) * sizeof(float);
+        if (lds_bytes > 64 * 1024) {   // more dynamic LDS than the default cap: opt in, once per device
+            static bool raised[64] = {};
+            int dev = 0;
+            FMRX_HIP(hipGetDevice(&dev));
+            if (dev < 0 || dev >= 64 || !raised[dev]) {
+                FMRX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_lds_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+                if (dev >= 0 && dev < 64) raised[dev] = true;
+            }
+        }
+        const long n_tiles = static_cast<long>((n_out + kLT - 1) / kLT);
+        const unsigned grid = static_cast<unsigned>(n_tiles < 256 ? n_tiles : 256);
+        for (int pass = 0; pass < pl.npass; pass++) {
+            hipLaunchKernelGGL(resample_lds_kernel, dim3(grid), dim3(kLT), lds_bytes, stream, d_x - delay,
+                               static_cast<long>(n_in), static_cast<long>(n_out), pl.table.p, pl.J, pl.JP, pl.decim,
+                               pl.upsamp, pl.span_l, pass * pl.W, pl.W, pass == 0, pass == pl.npass - 1, n_tiles, d_y);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return fail(FMRX_EHIP, "launch resample_lds_kernel: %s", hipGetErrorString(e));
+        }
+        return FMRX_OK;
+    }
     const unsigned grid = static_cast<unsigned>((n_out + kNT - 1) / kNT);
     hipLaunchKernelGGL(resample_poly_kernel, dim3(grid), dim3(kNT), pl.span * sizeof(float), stream, d_x - delay,
                        static_cast<long>(n_in), static_cast<long>(n_out), pl.table.p, pl.J, pl.JP, pl.decim, pl.upsamp,

@@ -133,6 +133,27 @@ def test_resampler_stage(fmrx, oracle, U, D, n):
     bits_equal(y2, yo); bits_equal(st3, sto)
 
 
+@pytest.mark.parametrize("U,D,n", [(147, 800, 800 * 500), (441, 3200, 3200 * 160), (4, 25, 25 * 20000)])
+def test_resampler_lds_table_kernel(fmrx, oracle, U, D, n, monkeypatch):
+    """Blocks with >= 65 536 outputs run the LDS-resident-table kernel (modes 2 / 3: one / two passes
+    over the taps; the partial sum of a pass goes through the output as a float): bit-exact against
+    the oracle and against the L2-table kernel, including the carried state."""
+    rng = np.random.default_rng(U)
+    x = rng.standard_normal(2 * n).astype(np.float32)
+    h = fmrx.impulseResponseLPF(240e3 * U, 16e3, 101 * U)
+    st = np.zeros(101 * U - 1, np.float32)
+    st[U - 1::U] = rng.standard_normal(100).astype(np.float32)
+    y1, s1 = fmrx.convolveBlockResampleFIR(x[:n], h, st, D, U)
+    y2, s2 = fmrx.convolveBlockResampleFIR(x[n:], h, s1, D, U)
+    yo1, so1 = oracle.convolve_block_resample_fir(x[:n], h, st, D, U)
+    yo2, so2 = oracle.convolve_block_resample_fir(x[n:], h, so1, D, U)
+    assert len(y1) >= 65536
+    bits_equal(y1, yo1); bits_equal(y2, yo2); bits_equal(s2[U - 1::U], so2[U - 1::U])
+    monkeypatch.setenv("FMRX_RESAMPLE_L2", "1")
+    y3, _ = fmrx.convolveBlockResampleFIR(x[:n], h, st, D, U)
+    bits_equal(y3, y1)
+
+
 def test_maximum_tap_count_and_non_finite_samples(fmrx, oracle):
     """The reference's tap count is an unsigned short: 65 535 taps is the maximum.  NaN / Inf samples
     must poison exactly the outputs whose window contains them, as in the reference."""
