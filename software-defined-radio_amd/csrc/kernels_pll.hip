@@ -172,36 +172,39 @@ __global__ void pll_check_kernel(const float *__restrict__ seg, long nseg, unsig
     }
 }
 
-__device__ inline long pll_next_bad(const unsigned long long *mask, long from, long nseg)
+// Repair (a no-op when every segment merged).  A mismatching segment whose predecessor is valid is
+// walked again from the predecessor's (true) end state; then its successor is judged again against
+// the new end state.  Mismatching segments that are not neighbours do not depend on each other, so
+// every round repairs all of them at once, one lane each, and a run of r consecutive bad segments
+// takes r rounds: typically one or two rounds of one segment's time instead of one lane walking all
+// of them in turn.  The result is the serial recurrence's, whatever the order.  Then publish the
+// block's end state.
+constexpr int kRepairThreads = 1024;
+__global__ __launch_bounds__(kRepairThreads) void pll_repair_kernel(
+    const float *__restrict__ in, long n, float *__restrict__ out, float *__restrict__ state, PllCoef c, int L, long nseg,
+    float *__restrict__ seg, unsigned long long *__restrict__ badmask, float tol_phase_base, float tol_integ,
+    unsigned *__restrict__ n_repaired, float *__restrict__ hdr)
 {
-    for (long wd = from / 64; wd * 64 < nseg; wd++) {
-        unsigned long long m = mask[wd];
-        if (wd == from / 64) m &= ~0ull << (from % 64);
-        if (m) {
-            const long sg = wd * 64 + __ffsll(static_cast<long long>(m)) - 1;
-            return sg < nseg ? sg : nseg;
-        }
-    }
-    return nseg;
-}
-
-// Serial repair (a no-op when every segment merged): from each mismatching segment walk the
-// recurrence from the true state until it is again bit-identical to what the next lane started
-// from -- from there on that lane's (and its successors') results are the serial ones.  Then
-// publish the block's end state.
-__global__ void pll_repair_kernel(const float *__restrict__ in, long n, float *__restrict__ out, float *__restrict__ state,
-                                  PllCoef c, int L, long nseg, float *__restrict__ seg,
-                                  const unsigned long long *__restrict__ badmask, float tol_phase_base, float tol_integ,
-                                  unsigned *__restrict__ n_repaired, float *__restrict__ hdr)
-{
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    __shared__ int any_todo;
     const float tol_phase = pll_phase_tol(tol_phase_base, state, n, c);
-    long sg = pll_next_bad(badmask, 1, nseg);
+    auto is_bad = [&](long sg) { return (badmask[sg / 64] >> (sg % 64)) & 1ull; };
     unsigned repaired = 0;
-    while (sg < nseg) {
-        PllState s = load_state(seg + (sg - 1) * 16);   // true state at the start of segment sg
-        bool merged = false;
-        while (!merged && sg < nseg) {
+    for (;;) {
+        if (threadIdx.x == 0) any_todo = 0;
+        __syncthreads();
+        // this round's work is fixed before anything changes: bad segments with a valid predecessor
+        // (their successors are then not in the round, so a lane's updates touch nobody else's input)
+        constexpr int kMaxPer = 8;                     // segments per lane and round (nseg <= 8192 per round; more: next round)
+        long todo[kMaxPer];
+        int nt = 0;
+        for (long sg = 1 + threadIdx.x; sg < nseg && nt < kMaxPer; sg += kRepairThreads)
+            if (is_bad(sg) && !is_bad(sg - 1)) todo[nt++] = sg;
+        if (nt) any_todo = 1;
+        __syncthreads();
+        if (!any_todo) break;
+        for (int i = 0; i < nt; i++) {
+            const long sg = todo[i];
+            PllState s = load_state(seg + (sg - 1) * 16);   // true state at the start of segment sg
             const long a = sg * L, b = a + L < n ? a + L : n;
             for (long k = a; k < b; k++) {
                 pll_step<true>(s, in[k], c);
@@ -209,20 +212,26 @@ __global__ void pll_repair_kernel(const float *__restrict__ in, long n, float *_
             }
             store_state(seg + sg * 16, s);
             repaired++;
-            sg++;
-            if (sg < nseg)
-                merged = fabsf(seg[sg * 16 + 9] - s.phase) <= tol_phase && fabsf(seg[sg * 16 + 8] - s.integ) <= tol_integ;
+            atomicAnd(badmask + sg / 64, ~(1ull << (sg % 64)));
+            if (sg + 1 < nseg) {
+                const bool merged = fabsf(seg[(sg + 1) * 16 + 9] - s.phase) <= tol_phase &&
+                                    fabsf(seg[(sg + 1) * 16 + 8] - s.integ) <= tol_integ;
+                if (merged) atomicAnd(badmask + (sg + 1) / 64, ~(1ull << ((sg + 1) % 64)));
+                else atomicOr(badmask + (sg + 1) / 64, 1ull << ((sg + 1) % 64));
+            }
         }
-        // lane sg started from the true state: it and its successors are valid up to the next mark
-        sg = pll_next_bad(badmask, sg + 1, nseg);
+        __threadfence();
+        __syncthreads();
     }
-    // remember where this call's phase started, for the next call's extrapolation
-    hdr[5] = state[1];
-    hdr[6] = static_cast<float>(n);
-    hdr[7] = 1.0f;
-    PllState e = load_state(seg + (nseg - 1) * 16);
-    store_state(state, e);
     if (n_repaired && repaired) atomicAdd(n_repaired, repaired);
+    if (threadIdx.x == 0) {
+        // remember where this call's phase started, for the next call's extrapolation
+        hdr[5] = state[1];
+        hdr[6] = static_cast<float>(n);
+        hdr[7] = 1.0f;
+        PllState e = load_state(seg + (nseg - 1) * 16);
+        store_state(state, e);
+    }
 }
 
 PllCoef make_coef(float freq, float Fs, float ncoScale, float phaseAdjust, float normBandwidth)
@@ -282,7 +291,7 @@ int k_fm_pll_parallel(const float *d_in, size_t n, float *d_out, float *d_state,
     hipLaunchKernelGGL(pll_check_kernel, dim3(grid), dim3(64), 0, s, seg, nseg, badmask, kPllTolPhase, kPllTolInteg,
                        reinterpret_cast<unsigned *>(d_scratch), d_state, static_cast<long>(n), c);
     FMRX_LAUNCH_CHECK("pll_check");
-    hipLaunchKernelGGL(pll_repair_kernel, dim3(1), dim3(64), 0, s, d_in, static_cast<long>(n), d_out, d_state, c, L, nseg, seg,
+    hipLaunchKernelGGL(pll_repair_kernel, dim3(1), dim3(kRepairThreads), 0, s, d_in, static_cast<long>(n), d_out, d_state, c, L, nseg, seg,
                        badmask, kPllTolPhase, kPllTolInteg, n_repaired, d_scratch);
     FMRX_LAUNCH_CHECK("pll_repair");
     return FMRX_OK;

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Profiling target: mode 0 stereo, 12 x 1,024,000-sample blocks per step, one cold step then 8 streaming steps."""
+import importlib, os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+fmrx = importlib.import_module("software-defined-radio_amd")
+synth = importlib.import_module("software-defined-radio_amd.synth")
+mode = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+p = fmrx.modeParams(mode)
+per_blk = {0: 20, 1: 20, 2: 18, 3: 15}[mode] * p.block_bytes
+iq = torch.from_numpy(synth.synth_fm_u8(per_blk // 2 * 3, p.rf_Fs, seed=0x3D74 + mode)).cuda().repeat(4)
+n_bytes = iq.numel()
+pl = fmrx.Pipeline(mode, 2, max_block_bytes=n_bytes)
+na = pl.n_audio(n_bytes)
+d_a = torch.empty(2 * na, dtype=torch.float32, device="cuda"); d_p = torch.empty(2 * na, dtype=torch.int16, device="cuda")
+s = torch.cuda.current_stream().cuda_stream
+pl.process_dev(iq.data_ptr(), n_bytes, d_a.data_ptr(), d_p.data_ptr(), stream=s)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+K = 8
+for _ in range(K):
+    pl.process_dev(iq.data_ptr(), n_bytes, d_a.data_ptr(), d_p.data_ptr(), stream=s)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / K
+print(f"mode {mode} stereo streaming: {dt*1e3:.3f} ms per {n_bytes//2} samples = {n_bytes/2/dt/1e6:.0f} MS/s = {n_bytes/2/dt/p.rf_Fs:.0f} x real time; pll diag {pl.pll_diagnostics()}")
