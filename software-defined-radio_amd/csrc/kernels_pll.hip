@@ -146,11 +146,20 @@ __global__ void pll_segments_kernel(const float *__restrict__ in, long n, float 
 // The loop cannot tell phases apart that round to the same float32 trigArg, so the merge
 // tolerance follows that grid: base + 2 ulp(trigArg) at the end of the block (ulp grows from 1e-3
 // at 1e4 rad to 0.25 at 3e6 rad -- the reference's own resolution loss).
-__device__ __forceinline__ float pll_phase_tol(float base, const float *state, long n, const PllCoef &c)
+__device__ __forceinline__ float pll_trig_ulp(const float *state, long n, const PllCoef &c)
 {
     const float top = static_cast<float>(c.w * (static_cast<double>(state[5]) + static_cast<double>(n)));
-    const float ulp = __uint_as_float((__float_as_uint(top) & 0x7f800000u)) * 1.1920929e-7f;   // 2^(e-23)
-    return base + 2.0f * ulp;
+    return __uint_as_float((__float_as_uint(top) & 0x7f800000u)) * 1.1920929e-7f;   // 2^(e-23)
+}
+__device__ __forceinline__ float pll_phase_tol(float base, const float *state, long n, const PllCoef &c)
+{
+    return base + 2.0f * pll_trig_ulp(state, n, c);
+}
+// the integrator moves by Ki * (phase error) per sample, and the phase error is only known to that
+// grid: two trajectories cannot agree better than a couple of such steps
+__device__ __forceinline__ float pll_integ_tol(float base, const float *state, long n, const PllCoef &c)
+{
+    return base + 2.0f * c.Ki * pll_trig_ulp(state, n, c);
 }
 
 // mark every segment whose start state differs from its predecessor's end state by more than the
@@ -162,6 +171,7 @@ __global__ void pll_check_kernel(const float *__restrict__ seg, long nseg, unsig
     const long sg = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (sg < 1 || sg >= nseg) return;
     const float tol_phase = pll_phase_tol(tol_phase_base, state, n, c);
+    tol_integ = pll_integ_tol(tol_integ, state, n, c);
     const float di = fabsf(seg[sg * 16 + 8] - seg[(sg - 1) * 16 + 0]);
     const float dp = fabsf(seg[sg * 16 + 9] - seg[(sg - 1) * 16 + 1]);
     if (!(dp <= tol_phase && di <= tol_integ)) {
@@ -187,6 +197,7 @@ __global__ __launch_bounds__(kRepairThreads) void pll_repair_kernel(
 {
     __shared__ int any_todo;
     const float tol_phase = pll_phase_tol(tol_phase_base, state, n, c);
+    tol_integ = pll_integ_tol(tol_integ, state, n, c);
     auto is_bad = [&](long sg) { return (badmask[sg / 64] >> (sg % 64)) & 1ull; };
     unsigned repaired = 0;
     for (;;) {
@@ -273,7 +284,15 @@ size_t pll_parallel_scratch_floats(size_t n)
 int k_fm_pll_parallel(const float *d_in, size_t n, float *d_out, float *d_state, float freq, float Fs, float ncoScale,
                       float phaseAdjust, float normBandwidth, float *d_scratch, hipStream_t s)
 {
-    const int L = kPllSegment, W = kPllWarmup;
+    int L = kPllSegment, W = kPllWarmup;
+    if (const char *e = std::getenv("FMRX_PLL_WARMUP")) {    // tuning: warm-up samples per lane
+        const int v = std::atoi(e);
+        if (v >= 0 && v <= 65536) W = v;
+    }
+    if (const char *e = std::getenv("FMRX_PLL_SEGMENT")) {   // tuning: samples per lane (>= kPllSegment: scratch is sized for that)
+        const int v = std::atoi(e);
+        if (v >= kPllSegment && v <= 65536) L = v;
+    }
     if (n < static_cast<size_t>(4 * L))   // nothing to gain
         return k_fm_pll(d_in, n, d_out, d_state, freq, Fs, ncoScale, phaseAdjust, normBandwidth, 1, s);
     const PllCoef c = make_coef(freq, Fs, ncoScale, phaseAdjust, normBandwidth);

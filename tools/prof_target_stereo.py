@@ -23,4 +23,4 @@ for _ in range(K):
     pl.process_dev(iq.data_ptr(), n_bytes, d_a.data_ptr(), d_p.data_ptr(), stream=s)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
-print(f"mode {mode} stereo streaming: {dt*1e3:.3f} ms per {n_bytes//2} samples = {n_bytes/2/dt/1e6:.0f} MS/s = {n_bytes/2/dt/p.rf_Fs:.0f} x real time; pll diag {pl.pll_diagnostics()}")
+print(f"W={os.environ.get('FMRX_PLL_WARMUP')} L={os.environ.get('FMRX_PLL_SEGMENT')} mode {mode} stereo streaming: {dt*1e3:.3f} ms per {n_bytes//2} samples = {n_bytes/2/dt/1e6:.0f} MS/s = {n_bytes/2/dt/p.rf_Fs:.0f} x real time; pll diag {pl.pll_diagnostics()}")
