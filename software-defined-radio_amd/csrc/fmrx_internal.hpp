@@ -78,10 +78,15 @@ struct FePlan {
     bool mfma = false;
     DevBuf<int32_t> a_img;
     float scale_lo = 0.0f;
+    DevBuf<uint8_t> silence;   // hist_bytes bytes of 128: the history of a stream that starts here
 };
+// FMRX_FE_VARIANT=valu selects the vector-ALU kernels (kernels_fe.hip) instead of the matrix-core ones;
+// read per call so one process can A/B them.
+bool fe_variant_mfma();
 constexpr int kFeMfmaDigits = 3;   // base-256 digits per tap: 24-bit fixed point
 int fe_plan_init(FePlan &pl, const float *h, int taps, int decim);
-// Matrix-core front end + discriminator: same contract as fe_demod_launch.
+// Matrix-core front end + discriminator: same contract as fe_demod_launch; d_demod may be NULL when
+// only the IF stream is wanted (d_if != NULL).
 int fe_mfma_plan_init(FePlan &pl, const float *h, int taps, int decim);
 bool fe_mfma_available(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist);
 int fe_mfma_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist, const float *d_prev,

@@ -598,6 +598,11 @@ int fe_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uin
     if (n_samples / pl.decim == 0) return FMRX_OK;
     const bool aligned = (reinterpret_cast<uintptr_t>(d_iq) % 16 == 0) && ((2 * n_samples) % 16 == 0) &&
                          (!d_hist || reinterpret_cast<uintptr_t>(d_hist) % 16 == 0);
+    if (aligned && !force_generic && fe_variant_mfma() &&
+        fe_mfma_available(pl, d_iq, n_samples, d_hist ? d_hist : pl.silence.p))
+        // matrix-core kernel, IF stream only (S1: 2 + 8/D bytes per sample)
+        return fe_mfma_launch(pl, d_iq, n_samples, d_hist ? d_hist : pl.silence.p, nullptr, nullptr, d_if, nullptr, nullptr,
+                              stream);
     if (pl.fast && aligned && !force_generic) {
         // the IF-only kernels read just the last 2*(taps-1+lead) bytes of the history
         const uint8_t *h1 = d_hist ? d_hist + (pl.hist_bytes - fe_hist_base(pl.taps)) : nullptr;

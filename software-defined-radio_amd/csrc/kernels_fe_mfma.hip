@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256, MINB) void fe_mfma_kernel(
         // were full).  Under-counting stores only waits longer; without P tiles behind, wait for all.
         if (steady) {
             if (it < C::P) wait_vmcnt<C::YOUNGER>();
-            else if (with_if) wait_vmcnt<C::YOUNGER + 2 * C::P>();
+            else if (with_if && demod) wait_vmcnt<C::YOUNGER + 2 * C::P>();
             else wait_vmcnt<C::YOUNGER + C::P>();
         } else {
             wait_vmcnt<0>();
@@ -226,16 +226,19 @@ __global__ __launch_bounds__(256, MINB) void fe_mfma_kernel(
             pi = ovi;
             pq = ovq;
         }
-        const float d0 = demod_fast(v[0], v[1], pi, pq);
-        const float d1 = demod_fast(v[2], v[3], v[0], v[1]);
+        float d0 = 0.0f, d1 = 0.0f;
+        if (demod) {                                           // wave-uniform: the IF-only form skips the discriminator
+            d0 = demod_fast(v[0], v[1], pi, pq);
+            d1 = demod_fast(v[2], v[3], v[0], v[1]);
+        }
 
         if (col > 0 && o < n_out && (!(DBG & 1) || d0 == 1234.5f)) {
             if (o + 1 < n_out) {
-                *reinterpret_cast<f2 *>(demod + o) = (f2){d0, d1};
+                if (demod) *reinterpret_cast<f2 *>(demod + o) = (f2){d0, d1};
                 if (with_if) *reinterpret_cast<f4 *>(y_if + 2 * o) = (f4){v[0], v[1], v[2], v[3]};
                 if (prev_out && o + 2 == n_out) *prev_out = make_float2(v[2], v[3]);
             } else {
-                demod[o] = d0;
+                if (demod) demod[o] = d0;
                 if (with_if) *reinterpret_cast<f2 *>(y_if + 2 * o) = (f2){v[0], v[1]};
                 if (prev_out) *prev_out = make_float2(v[0], v[1]);
             }
@@ -680,9 +683,17 @@ int fe_mfma_plan_init(FePlan &pl, const float *h, int taps, int decim)
 #undef X
     if (!pl.mfma) return FMRX_OK;
     pl.scale_lo = static_cast<float>(std::ldexp(1.0, -s - 7));          // 2^-s for the taps, /128 for the samples
+    FMRX_TRY(pl.silence.alloc(pl.hist_bytes));
+    FMRX_HIP(hipMemset(pl.silence.p, 128, pl.hist_bytes));
     FMRX_TRY(pl.a_img.alloc((img.size() + 3) / 4));
     FMRX_HIP(hipMemcpy(pl.a_img.p, img.data(), img.size(), hipMemcpyHostToDevice));
     return FMRX_OK;
+}
+
+bool fe_variant_mfma()
+{
+    const char *e = std::getenv("FMRX_FE_VARIANT");
+    return !(e && std::strcmp(e, "valu") == 0);
 }
 
 bool fe_mfma_available(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist)
@@ -695,7 +706,7 @@ int fe_mfma_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, cons
                    float *d_demod, float *d_if, float *d_prev_out, uint8_t *d_hist_next, hipStream_t stream)
 {
     if (n_samples / pl.decim == 0) return FMRX_OK;
-    if (!d_demod) return fail(FMRX_EINVAL, "fe_mfma_launch: null argument");
+    if (!d_demod && !d_if) return fail(FMRX_EINVAL, "fe_mfma_launch: no output");
     if (const char *e = std::getenv("FMRX_FE_MFMA_TUNE")) {   // "<workgroups per CU><tiles in flight>", (101,10) only
         const int v = std::atoi(e);
 #define Y(B_, P_) \

@@ -88,14 +88,6 @@ __global__ void hist_update_kernel(const uint8_t *__restrict__ old_hist, const u
     new_hist[i] = src >= 0 ? x[src] : old_hist[hb + src];
 }
 
-// FMRX_FE_VARIANT=valu selects the vector-ALU fused kernel (kernels_fe.hip) instead of the
-// matrix-core one; read per call so one process can A/B them.
-bool fe_variant_mfma()
-{
-    const char *e = std::getenv("FMRX_FE_VARIANT");
-    return !(e && std::strcmp(e, "valu") == 0);
-}
-
 // The fused mono kernel gives each wave whole batches of 256 audio samples; below this many audio
 // samples per call there are too few batches to fill the chip and the two-kernel path is used.
 // FMRX_FUSED_MIN_AUDIO overrides (0 = always fuse when possible, a huge value = never).

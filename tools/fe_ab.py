@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""A/B the front-end kernel variants in ONE process, interleaved rounds
-(cdna_hip_programming.md rule 24), on the bench workload's input.
+"""A/B the IF-only front end (S1: u8 I/Q -> f32 IF I,Q; 2.8 B/sample): matrix-core kernel vs the
+vector-ALU kernel, in ONE process, interleaved rounds (cdna_hip_programming.md rule 24), on the bench
+workload's input.
     python tools/fe_ab.py [blocks=256] [rounds=5]
 """
 import importlib
@@ -16,7 +17,7 @@ fmrx = importlib.import_module("software-defined-radio_amd")
 synth = importlib.import_module("software-defined-radio_amd.synth")
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 N = 1_024_000
 iq = torch.from_numpy(synth.synth_fm_u8(4 * N)).cuda().repeat(B // 4)
 n = iq.numel() // 2
@@ -28,7 +29,7 @@ s = torch.cuda.current_stream().cuda_stream
 res = {}
 outs = {}
 for rnd in range(ROUNDS):
-    for v in ("1", "2"):
+    for v in ("mfma", "valu"):
         os.environ["FMRX_FE_VARIANT"] = v
         for _ in range(3):
             plan.run_dev(iq.data_ptr(), n, hist.data_ptr(), d_if.data_ptr(), stream=s)
@@ -41,7 +42,7 @@ for rnd in range(ROUNDS):
         torch.cuda.synchronize()
         res.setdefault(v, []).append(e0.elapsed_time(e1) / 10)
         outs[v] = d_if.clone()
-assert torch.equal(outs["1"], outs["2"]), "variants disagree"
+print("max |mfma - valu| IF sample:", float((outs["mfma"] - outs["valu"]).abs().max()))
 for v, ts in res.items():
     ms = float(np.median(ts))
     print(f"variant {v}: median {ms:.4f} ms  min {min(ts):.4f}  -> {n / ms / 1e3:.0f} MS/s, "
