@@ -156,6 +156,9 @@ def main() -> int:
     ap.add_argument("--settle-ms", type=float, default=400.0,
                     help="untimed steps run for this long before the warm-up, so that the clocks the chip holds under "
                          "this load are reached (a step is ~0.13 ms; the first ~300 after idle run up to 30 %% slower)")
+    ap.add_argument("--fe-variant", default="mfma", choices=["mfma", "valu"],
+                    help="mfma (default): matrix-core kernels, whole mono chain fused; valu: the vector-ALU kernels "
+                         "(front end + discriminator, then the audio kernel) -- the 'no MFMA' form of the north star")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -163,6 +166,8 @@ def main() -> int:
     ap.add_argument("--all-on-device0", action="store_true", help="rehearsal: every rank uses GPU 0")
     args = ap.parse_args()
 
+    if args.fe_variant == "valu":
+        os.environ["FMRX_FE_VARIANT"] = "valu"     # read per call by libfmrx
     import torch
 
     if not torch.cuda.is_available():
@@ -218,7 +223,10 @@ def main() -> int:
     out = None
     if rank == 0:
         value = job_throughput(world, n_samples, args.steps, elapsed)
-        fe_bytes = FE_BYTES_PER_SAMPLE * n_samples
+        # dominant kernel: the fused mono kernel (S3: 2.12 B/sample) or, for --fe-variant valu, the
+        # vector-ALU front end + discriminator (S2: 2 B in + 4/10 B of f32 demod out)
+        bytes_per_sample = FE_BYTES_PER_SAMPLE if fused else 2.0 + 4.0 / 10.0
+        fe_bytes = bytes_per_sample * n_samples
         achieved = fe_bytes / (fe_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "fe_traffic.json")   # PMC-derived bytes per launch, if collected
@@ -242,11 +250,12 @@ def main() -> int:
                 "realtime_channels_equiv": round(value / 2.4, 0), "settle_ms": args.settle_ms,
             },
             "roofline": {
-                "kernel": "mono_fused_kernel<101,10,101,5> (u8 I/Q -> 101-tap FIR, decimate 10 (int8 MFMA) -> FM "
-                          "discriminator -> 101-tap audio FIR, decimate 5 (f32 MFMA) -> f32 audio + s16 PCM)",
-                "algorithmic_bytes_per_sample": FE_BYTES_PER_SAMPLE,
+                "kernel": ("mono_fused_kernel<101,10,101,5> (u8 I/Q -> 101-tap FIR, decimate 10 (int8 MFMA) -> FM "
+                           "discriminator -> 101-tap audio FIR, decimate 5 (f32 MFMA) -> f32 audio + s16 PCM)") if fused else
+                          "fe_demod_kernel<101,10,8> (u8 I/Q -> 101-tap FIR, decimate 10 (v_pk_fma_f32) -> FM discriminator -> f32 demod)",
+                "algorithmic_bytes_per_sample": round(bytes_per_sample, 2), "fe_variant": args.fe_variant,
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic if fused else None,
                 "algorithmic_bytes_per_launch": int(fe_bytes), "avg_launch_ms": round(fe_ms, 4),
                 "launches_timed": cnt, "event_pair_overhead_ms": round(pair_ms, 4) if fused else None,
                 "useful_tflops": round(FE_FLOP_PER_SAMPLE * n_samples / (fe_ms * 1e-3) / 1e12, 2),
