@@ -221,6 +221,46 @@ def main() -> int:
     fe_ms = tsum["front_end_ms"] / cnt - pair_ms
     pl.set_profiling(False)
 
+    # ---- side legs, after the timed region, N=1 only: (1) the same workload through the vector-ALU
+    #      kernels (the north star's "no MFMA" form), (2) what a plain device-to-device copy reaches on
+    #      this box (report the fraction of measured copy bandwidth next to the 8 TB/s peak) ----
+    north_star_form = copy_gbs = None
+    if world == 1 and args.fe_variant == "mfma":
+        os.environ["FMRX_FE_VARIANT"] = "valu"
+        for _ in range(200):
+            step()
+        torch.cuda.synchronize()
+        pl.set_profiling(PROF_EVERY)
+        k2 = max(20, min(args.steps, 50))
+        t0 = time.perf_counter()
+        for _ in range(k2):
+            step()
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t0
+        t2, c2 = pl.timing_sum((k2 + PROF_EVERY - 1) // PROF_EVERY)
+        pl.set_profiling(False)
+        os.environ.pop("FMRX_FE_VARIANT")
+        fe2 = (t2["front_end_ms"] - t2["rest_ms"]) / c2
+        north_star_form = {
+            "fe_variant": "valu", "value": round(n_samples * k2 / dt2 / 1e6, 1), "unit": "MS/s",
+            "kernel": "fe_demod_kernel<101,10,8> (v_pk_fma_f32 FIR + discriminator, S2: 2.4 B/sample) then audio_fir_kernel",
+            "avg_launch_ms": round(fe2, 4), "achieved": round(2.4 * n_samples / (fe2 * 1e-3) / 1e9, 1),
+            "frac": round(2.4 * n_samples / (fe2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "steps": k2,
+        }
+    if world == 1:
+        src = torch.empty(128 * 1024 * 1024, dtype=torch.float32, device="cuda").normal_()
+        dst = torch.empty_like(src)
+        for _ in range(5):
+            dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 2 * src.numel() * 4 * 20 / (e0.elapsed_time(e1) * 1e-3) / 1e9     # bytes read + written
+        del src, dst
+
     out = None
     if rank == 0:
         value = job_throughput(world, n_samples, args.steps, elapsed)
@@ -261,8 +301,13 @@ def main() -> int:
                 "launches_timed": cnt, "event_pair_overhead_ms": round(pair_ms, 4),
                 "useful_tflops": round(FE_FLOP_PER_SAMPLE * n_samples / (fe_ms * 1e-3) / 1e12, 2),
                 "stage_ms": {k: round(v / cnt, 4) for k, v in tsum.items()},
+                "measured_copy": None if copy_gbs is None else {
+                    "what": "torch d2d copy of 512 MiB f32, bytes read + written per second", "GB/s": round(copy_gbs, 1),
+                    "frac_of_copy": round(achieved / copy_gbs, 4)},
             },
         }
+        if north_star_form is not None:
+            out["north_star_form"] = north_star_form
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
     if dist is not None:
