@@ -379,6 +379,10 @@ __device__ __forceinline__ void fu_dma_slot(const uint8_t *__restrict__ x, const
     }
 }
 
+// PF / DRF / KPTF override P / DR / KPT, DBG compiles parts out -- ablation variants behind FMRX_FUSED_TUNE
+// (tools/fused_tune.py; DESIGN.md section 5 quotes them), never dispatched by default.  DBG bits: 1 = no audio
+// work at all, 2 = the audio MFMAs replaced by one v_fma each, 4 = no byte flip (wrong results, timing
+// only), 8 = audio stores compiled out.
 template <int T, int D, int TA, int DA, int PF = 0, int DRF = 0, int DBG = 0, int KPTF = 0>
 __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
     const uint8_t *__restrict__ x, const uint8_t *__restrict__ hist_end, long n_bytes, const i4 *__restrict__ a_img,
