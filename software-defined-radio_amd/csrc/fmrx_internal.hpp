@@ -190,7 +190,7 @@ int k_fm_pll(const float *d_in, size_t n, float *d_out, float *d_state, float fr
 // parallel-in-time form (fast math): segments with warm-up, bit-for-bit verification against the
 // serial trajectory and serial repair where the loop was not locked.  d_scratch: pll_parallel_scratch_floats(n)
 // floats; d_scratch[2] (as u32) counts blocks that needed a repair (diagnostic).
-constexpr int kPllSegment = 1024, kPllWarmup = 1024;
+constexpr int kPllSegment = 512, kPllWarmup = 768;
 // merge tolerance between a lane's warmed-up state and the true state (see kernels_pll.hip)
 constexpr float kPllTolPhase = 1e-2f, kPllTolInteg = 1e-4f;
 size_t pll_parallel_scratch_floats(size_t n);
