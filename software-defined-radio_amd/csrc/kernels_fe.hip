@@ -15,8 +15,12 @@
 //                      next tile prefetched into registers
 //   fe_fir_kernel      IF-only, one tile per workgroup (baseline; FMRX_FE_VARIANT=1)
 //
-// The core (CDNA4 / gfx950, wave64, VALU packed FP32; no MFMA -- a 1-D FIR has a
-// one-column "B matrix"):
+// This file is the vector-ALU generation of the front end (the north star's "no MFMA" form): kept,
+// tested, selected by FMRX_FE_VARIANT=valu.  The default kernels are the matrix-core ones of
+// kernels_fe_mfma.hip (int8 MFMA on the raw bytes, exact integer arithmetic), which are HBM-bound
+// where this one is VALU-bound.
+//
+// The core (CDNA4 / gfx950, wave64, VALU packed FP32):
 //
 //  * Bytes stay bytes until the register file: a tile's raw I/Q bytes are staged
 //    in LDS (10 KB per wave tile), never inflated to floats in memory.  HBM
