@@ -375,6 +375,38 @@ def test_fused_mono_kernel_many_batches_per_wave(fmrx, oracle):
     assert not out["audio"].any() and not out["pcm16"].any()
 
 
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_random_block_sizes_hand_state_between_kernels(fmrx, oracle, mode, monkeypatch):
+    """40 blocks of random sizes (1 ... 3000 units) through one handle: with the fused kernel enabled
+    from 2048 audio samples up, consecutive blocks alternate between the fused kernel and the
+    front-end + audio kernel pair, each picking up the other's carried state (byte history, last IF
+    sample, discriminator tail).  Audio of every block against the oracle streaming the same blocks."""
+    if os.environ.get("FMRX_FE_VARIANT") == "valu":
+        pytest.skip("fused kernel is a matrix-core kernel")
+    monkeypatch.setenv("FMRX_FUSED_MIN_AUDIO", "2048")
+    p = oracle.mode_params(mode, 101, 101, 101)
+    unit = int(2 * p.rf_decim * np.lcm(p.audio_decim, 8))
+    rng = np.random.default_rng(2024 + mode)
+    ks = [int(k) for k in np.concatenate([rng.integers(1, 40, 14), rng.integers(40, 3000, 20), [1, 2999, 3, 511, 512, 513]])]
+    rng.shuffle(ks)
+    floor = -(-2 * p.rf_decim * 104 // unit)          # the reference's n >= taps-1 contract on the audio stage
+    sizes = [unit * max(k, floor) for k in ks]
+    iq = oracle.synth_fm_u8(sum(sizes) // 2, rf_Fs=p.rf_Fs, seed=99 + mode)
+    pl = fmrx.Pipeline(mode, 1, max_block_bytes=max(sizes))
+    po = oracle.pipeline(mode, 1)
+    off, n_fused, got, want = 0, 0, [], []
+    for nb in sizes:
+        blk = iq[off:off + nb]
+        off += nb
+        out, ref = pl.process(blk), po.process(blk)
+        n_fused += len(ref["audio"]) >= 2048
+        assert_audio_close(out["audio"], ref["audio"], f"mode {mode} block of {nb} bytes at offset {off - nb}")
+        got.append(out["pcm16"]); want.append(oracle.pcm16(ref["audio"]))
+    assert_pcm_close(np.concatenate(got), np.concatenate(want))     # +-1 LSB, rare, over the whole stream
+    assert 5 < n_fused < len(sizes) - 5
+
+
 # ---------------------------------------------------------------------------
 # pipelines
 # ---------------------------------------------------------------------------
