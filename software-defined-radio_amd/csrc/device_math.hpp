@@ -38,12 +38,12 @@ __device__ __forceinline__ float demod_fast(float i, float q, float pi, float pq
 {
     const float ii = i * i, qq = q * q;
     const float den = ii + qq;
-    if (den == 0.0f) return 0.0f;
     const float a = i * (q - pq);
     const float b = q * (i - pi);
     const float num = a - b;
     const float sc = den < 8.6736174e-19f ? 1.8446744e19f : 1.0f;   // den < 2^-60 ? 2^64 : 1
-    return (num * sc) * __builtin_amdgcn_rcpf(den * sc);
+    const float quot = (num * sc) * __builtin_amdgcn_rcpf(den * sc);
+    return den == 0.0f ? 0.0f : quot;                                // select, not a branch: every lane runs both anyway
 }
 
 // PCM pack of src/threadMonoOnly.cpp:185-191: NaN -> 0 else (short)(a*16384).
