@@ -191,6 +191,7 @@ int k_fm_pll(const float *d_in, size_t n, float *d_out, float *d_state, float fr
 // serial trajectory and serial repair where the loop was not locked.  d_scratch: pll_parallel_scratch_floats(n)
 // floats; d_scratch[2] (as u32) counts blocks that needed a repair (diagnostic).
 constexpr int kPllSegment = 512, kPllWarmup = 768;
+constexpr int kPllHead = 1024;   // samples of a stream's first call walked serially (acquisition) before the lanes take over
 // merge tolerance between a lane's warmed-up state and the true state (see kernels_pll.hip)
 constexpr float kPllTolPhase = 1e-2f, kPllTolInteg = 1e-4f;
 size_t pll_parallel_scratch_floats(size_t n);

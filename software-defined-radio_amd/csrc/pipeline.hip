@@ -460,7 +460,9 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
             // segment lanes extrapolate from a locked state; later blocks start locked already
             size_t head = 0;
             if (!pl->pll_warm) {
-                head = n_if < 4096 ? n_if : 4096;
+                size_t head_len = kPllHead;
+                if (const char *e = std::getenv("FMRX_PLL_HEAD")) head_len = static_cast<size_t>(std::atol(e));   // tuning
+                head = n_if < head_len ? n_if : head_len;
                 FMRX_TRY(k_fm_pll(pl->carrier.p, head, pl->pll.p, pl->pll_state.p, 19e3f, static_cast<float>(p.if_Fs),
                                   2.0f, 0.0f, 0.01f, 1, s));
             }
