@@ -53,14 +53,25 @@ struct PllCoef {
 
 struct PllState {
     float integ, phase, fbI, fbQ, last, off;
+    float fr;   // FAST only: trigArg / 2 pi of the step that produced fbI/fbQ, reduced to [-0.5, 0.5] revolutions
 };
 
 template <bool FAST>
 __device__ __forceinline__ void pll_step(PllState &s, float v, const PllCoef &c)
 {
-    const float eI = v * s.fbI;
-    const float eQ = v * (-1 * s.fbQ);
-    const float eD = atan2f(eQ, eI);
+    float eD;
+    if (FAST && fabsf(v) > 1e-20f && fabsf(v) < 1e20f) {
+        // atan2f(v * -sin t, v * cos t) is -t for v > 0 and -t turned by pi for v < 0: no arctangent
+        // needed, and closer to the reference's value (which sees glibc's sin/cos of the same t) than the
+        // arctangent of the hardware sine and cosine.  Zero / non-finite / denormal-product samples
+        // take the library path below: there the reference's result hangs on signed zeros and infinities.
+        const float er = v > 0.0f ? -s.fr : (s.fr >= 0.0f ? 0.5f - s.fr : -0.5f - s.fr);
+        eD = er * 6.28318530717958647692f;
+    } else {
+        const float eI = v * s.fbI;
+        const float eQ = v * (-1 * s.fbQ);
+        eD = atan2f(eQ, eI);
+    }
     s.integ = s.integ + c.Ki * eD;
     const float pe = c.Kp * eD;
     s.phase = (s.phase + pe) + s.integ;
@@ -71,6 +82,7 @@ __device__ __forceinline__ void pll_step(PllState &s, float v, const PllCoef &c)
         const double inv2pi = 0.15915494309189533577;
         const double rev = static_cast<double>(trigArg) * inv2pi;
         const float fr = static_cast<float>(rev - rint(rev));          // [-0.5, 0.5] revolutions
+        s.fr = fr;
         s.fbI = __builtin_amdgcn_cosf(fr);
         s.fbQ = __builtin_amdgcn_sinf(fr);
         const double rev2 = static_cast<double>(sc + c.phaseAdjust) * inv2pi;
@@ -84,7 +96,8 @@ __device__ __forceinline__ void pll_step(PllState &s, float v, const PllCoef &c)
 
 __device__ __forceinline__ PllState load_state(const float *st)
 {
-    return PllState{st[0], st[1], st[2], st[3], st[4], st[5]};
+    // fr: the angle whose cosine / sine the carried feedback pair is
+    return PllState{st[0], st[1], st[2], st[3], st[4], st[5], atan2f(st[3], st[2]) * 0.15915494309189533577f};
 }
 __device__ __forceinline__ void store_state(float *st, const PllState &s)
 {
@@ -99,8 +112,11 @@ __global__ void pll_serial_kernel(const float *__restrict__ in, size_t n, float 
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     PllState s = load_state(state);
     out[0] = s.last;
+    float vn = n ? in[0] : 0.0f;                          // next sample, fetched one step ahead of the chain
     for (size_t k = 0; k < n; k++) {
-        pll_step<FAST>(s, in[k], c);
+        const float v = vn;
+        vn = in[k + 1 < n ? k + 1 : k];
+        pll_step<FAST>(s, v, c);
         out[k + 1] = s.last;
     }
     store_state(state, s);
@@ -129,15 +145,25 @@ __global__ void pll_segments_kernel(const float *__restrict__ in, long n, float 
         const float trigArg = static_cast<float>(c.w * static_cast<double>(s.off) + static_cast<double>(s.phase));
         const double rev = static_cast<double>(trigArg) * 0.15915494309189533577;
         const float fr = static_cast<float>(rev - rint(rev));
+        s.fr = fr;
         s.fbI = __builtin_amdgcn_cosf(fr);
         s.fbQ = __builtin_amdgcn_sinf(fr);
     }
-    for (; k < a; k++) pll_step<true>(s, in[k], c);       // warm-up (or exact replay from the block start)
+    // The recurrence is one long dependency chain; the samples it eats are not part of it.  They are
+    // fetched one step ahead so that a load's latency is never on the chain.
+    float vn = k < b ? in[k] : 0.0f;
+    for (; k < a; k++) {                                  // warm-up (or exact replay from the block start)
+        const float v = vn;
+        vn = in[k + 1 < b ? k + 1 : k];
+        pll_step<true>(s, v, c);
+    }
     seg[sg * 16 + 8] = s.integ;
     seg[sg * 16 + 9] = s.phase;
     if (sg == 0) out[0] = s0.last;
     for (; k < b; k++) {
-        pll_step<true>(s, in[k], c);
+        const float v = vn;
+        vn = in[k + 1 < b ? k + 1 : k];
+        pll_step<true>(s, v, c);
         out[k + 1] = s.last;
     }
     store_state(seg + sg * 16, s);
@@ -217,8 +243,11 @@ __global__ __launch_bounds__(kRepairThreads) void pll_repair_kernel(
             const long sg = todo[i];
             PllState s = load_state(seg + (sg - 1) * 16);   // true state at the start of segment sg
             const long a = sg * L, b = a + L < n ? a + L : n;
+            float vn = a < b ? in[a] : 0.0f;
             for (long k = a; k < b; k++) {
-                pll_step<true>(s, in[k], c);
+                const float v = vn;
+                vn = in[k + 1 < b ? k + 1 : k];
+                pll_step<true>(s, v, c);
                 out[k + 1] = s.last;
             }
             store_state(seg + sg * 16, s);
