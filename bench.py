@@ -282,7 +282,7 @@ def main() -> int:
             "metric": "I/Q MS/s through front-end FIR+decimate+demod(+audio) per job; % HBM roofline",
             "value": round(value, 1), "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "i8+f32" if fused else "f32", "data": "synthetic",
             "config": {
                 "workload": "configs[1]: mode 0 mono, 101-tap FE FIR+decimate(10) + FM discriminator + 101-tap audio "
                             "FIR+decimate(5) + s16 pack; synthetic 2.4 MS/s FM I/Q (u8), 1,024,000-sample blocks",
