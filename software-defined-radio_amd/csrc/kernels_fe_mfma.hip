@@ -557,7 +557,6 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
 #pragma unroll
                 for (int d = 0; d < F::NDIG; d++) acc[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[j][d], bs, acc[d], 0, 0, 0);
             }
-            if (sl) slice_mfma();
             float v[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -590,7 +589,12 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
             }
             slot = slot + 1 == C::NSLOT ? 0 : slot + 1;
             dpos = dpos + C::TILE_OUT == C::DR ? 0 : dpos + C::TILE_OUT;
-            if (sl) slice_done();
+            // the slice's MFMAs go last: issued here they run under the next tile's waits and LDS reads, issued
+            // right behind the front end's they would stand in front of its whole epilogue (a wave issues in order)
+            if (sl) {
+                slice_mfma();
+                slice_done();
+            }
             completed = !(DBG & 1) && t >= t0 && ((t + 1) % C::TB == 0 || t + 1 == n_tiles);
             t++;
         }
