@@ -321,13 +321,15 @@ struct FuCfg {
     static constexpr int REM_LANES = (TILE_BYTES % 1024) / 16;
     static constexpr int NP = NPF + (REM_LANES ? 1 : 0);
     static constexpr int P = PF ? PF : iclamp(6144 / TILE_BYTES, 2, 8);   // tiles in flight beyond the one being multiplied
-    static constexpr int NSLOT = P + 1;
+    // one slot more than tiles in flight: the DMA of tile t+P+1 is issued at the top of iteration t, into the
+    // slot tile t-1 left, before this iteration waits for its own data and reads its fragments
+    static constexpr int NSLOT = P + 2;
     static constexpr int RING = NSLOT * TILE_BYTES;                // byte ring: slot t holds bytes [t*TILE - FRONT, (t+1)*TILE - FRONT)
     static constexpr int PIECE0 = NPF ? 1024 : TILE_BYTES;
     // a tile reads its own slot and the head of the next one: that head must be one DMA piece
     static_assert(F::WIN - F::COL_BYTES <= PIECE0, "window overlap must fit the next slot's first piece");
     static_assert(64 * F::KSTEPS - F::COL_BYTES <= RING - TILE_BYTES, "K padding laps the ring");
-    static constexpr int YOUNGER = (NP - 1) + NP * (P - 1);        // DMA pieces younger than (next slot, piece 0)
+    static constexpr int YOUNGER = (NP - 1) + NP * P;              // DMA pieces younger than (next slot, piece 0) at the wait
     static_assert(YOUNGER <= 63, "vmcnt is 6 bits");
     static constexpr int AB_OUT = 256;                             // audio outputs per batch
     static constexpr int TB = AB_OUT * DA / TILE_OUT;              // tiles per batch
@@ -341,7 +343,8 @@ struct FuCfg {
     // K-steps per slice: whole groups of 4 (one ds_read_b128 per lane feeds 4 K-steps, see slice_load)
     static constexpr int KPT = KPTF ? KPTF : ((AK + TB - 3) / (TB - 2) + 3) / 4 * 4;
     static constexpr int NPH = (AK + KPT - 1) / KPT;               // slices per batch, <= TB - 2
-    static constexpr int DR = DRF ? DRF : 3072;                    // discriminator ring, floats (a multiple of TILE_OUT)
+    static constexpr int DR_MIN = AB_OUT * DA + TA - 1 + (4 * AK - AWIN) + (NPH + 1) * TILE_OUT;
+    static constexpr int DR = DRF ? DRF : (DR_MIN + TILE_OUT - 1) / TILE_OUT * TILE_OUT;   // discriminator ring, floats (whole tiles)
     static_assert(NPH <= TB - 2, "a batch must be done before the next one completes");
     static_assert(AB_OUT * DA + TA - 1 + (4 * AK - AWIN) + (NPH + 1) * TILE_OUT <= DR, "ring too small for the delayed multiply");
     static_assert(DR % TILE_OUT == 0, "tiles must not wrap inside");
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
         const int adr = (C::NSLOT - 1) * C::TILE_BYTES + lane_off + 64 * j;
         wrap_adr[j] = adr >= C::RING ? adr - C::RING : adr;
     }
-    int slot = 0;
+    int slot = 0, fill = C::P + 1;                             // ring slot of tile t / of tile t+P+1
     int dpos = C::TILE_OUT;                                    // ring position of tile t's first sample (wave-uniform)
     // the batch being multiplied (at most one): its accumulators, next slice, window, outputs
     bool pend = false;
@@ -526,9 +529,12 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
         bool completed = false;
         if (have_tile) {
             const bool sl = pend;                                  // a slice of the pending batch rides along (wave-uniform)
+            // keep P+1 tiles in flight behind this one: the slot of tile t-1 is free (its reads were waited for)
+            const bool steady = t + C::P + 1 <= t1;
+            if (steady) fu_dma_slot<C, F>(x, hist_end, n_bytes, t + C::P + 1, ring, fill, lane);
             // tile t's slot and the first piece of slot t+1 have landed (vmcnt counts in issue order; the
             // occasional output stores are not credited, which only waits longer)
-            if (t + C::P <= t1) wait_vmcnt<C::YOUNGER>();
+            if (steady) wait_vmcnt<C::YOUNGER>();
             else wait_vmcnt<0>();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -546,7 +552,6 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
             __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0): the slot may be refilled
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (t + C::P + 1 <= t1) fu_dma_slot<C, F>(x, hist_end, n_bytes, t + C::P + 1, ring, slot, lane);
 
             i4 acc[F::NDIG];
 #pragma unroll
@@ -588,6 +593,7 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
                 if (prev_out && o + 1 == n_out) *prev_out = make_float2(v[0], v[1]);
             }
             slot = slot + 1 == C::NSLOT ? 0 : slot + 1;
+            fill = fill + 1 == C::NSLOT ? 0 : fill + 1;
             dpos = dpos + C::TILE_OUT == C::DR ? 0 : dpos + C::TILE_OUT;
             // the slice's MFMAs go last: issued here they run under the next tile's waits and LDS reads, issued
             // right behind the front end's they would stand in front of its whole epilogue (a wave issues in order)
@@ -779,7 +785,7 @@ int mono_fused_launch(const FePlan &fe, const AudioPlan &au, const uint8_t *d_iq
         return launch_fused_mono<101, 10, 101, 5, P_, DR_, G_, K_>(fe, au, d_iq, n_samples, d_hist, d_prev, d_dhist_end,    \
                                                                   d_demod_tail, tail_keep, d_prev_out, d_audio, d_pcm, wrap, \
                                                                   d_hist_next, stream);
-        Y(2, 2, 0, 0, 0) Y(12, 2, 0, 1, 0) Y(3, 2, 2304, 0, 8) Y(4, 3, 2304, 0, 8) Y(82, 2, 0, 8, 0) Y(102, 2, 0, 10, 0)
+        Y(2, 2, 0, 0, 0) Y(12, 2, 0, 1, 0) Y(1, 1, 0, 0, 0) Y(82, 2, 0, 8, 0) Y(102, 2, 0, 10, 0)
 #undef Y
     }
 #define X(T_, D_, TA_, DA_)                                                                                          \
