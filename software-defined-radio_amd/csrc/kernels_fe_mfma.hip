@@ -36,6 +36,7 @@
 // tile's window overlaps its neighbour's by LEAD + K padding bytes (L2 hits), outputs are
 // written once.
 #include "device_math.hpp"
+#include "fe_mfma_host.hpp"
 #include "fmrx_internal.hpp"
 
 #include <cmath>
@@ -271,32 +272,6 @@ int launch_mfma(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const u
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FMRX_EHIP, "launch fe_mfma_kernel<%d,%d>: %s", T, D, hipGetErrorString(e));
     return FMRX_OK;
-}
-
-// Digit image of the taps in A-operand order: [kstep][digit][lane][16 bytes].  Lane (row m = lane&15,
-// quarter g = lane>>4) holds the coefficients that row applies to window bytes 64*kstep + 16*g + 0..15.
-// Row m -> output r = 2*(m/4) + (m%4)/2 of the column, channel c = m%2: the C layout
-// (row = 4*(lane>>4) + reg) then hands lane (col, g) the pair of outputs 2g, 2g+1 as (I,Q,I,Q).
-template <int T, int D>
-void build_image(const float *h, int s, std::vector<int8_t> &img)
-{
-    using C = MfCfg<T, D>;
-    img.assign(static_cast<size_t>(C::KSTEPS) * C::NDIG * 64 * 16, 0);
-    for (int j = 0; j < C::KSTEPS; j++)
-        for (int lane = 0; lane < 64; lane++)
-            for (int b = 0; b < 16; b++) {
-                const int m = lane & 15, g = lane >> 4;
-                const int r = 2 * (m / 4) + (m % 4) / 2, c = m % 2;
-                const int p = 64 * j + 16 * g + b;                      // window byte
-                const int e = C::FRONT + 2 * D * r + c - p;             // = 2k for the tap that meets it
-                if (e < 0 || (e & 1) || e / 2 > T - 1) continue;
-                long q = std::llround(std::ldexp(static_cast<double>(h[e / 2]), s));
-                for (int d = 0; d < C::NDIG; d++) {
-                    const long dig = ((q + 128) & 255) - 128;           // balanced digit in [-128, 127]
-                    img[((static_cast<size_t>(j) * C::NDIG + d) * 64 + lane) * 16 + b] = static_cast<int8_t>(dig);
-                    q = (q - dig) / 256;
-                }
-            }
 }
 
 // ============================================================================================
@@ -677,21 +652,16 @@ int launch_fused_mono(const FePlan &fe, const AudioPlan &au, const uint8_t *d_iq
 int fe_mfma_plan_init(FePlan &pl, const float *h, int taps, int decim)
 {
     pl.mfma = false;
-    double maxabs = 0.0;
-    for (int k = 0; k < taps; k++) {
-        if (!std::isfinite(h[k])) return FMRX_OK;                       // generic / VALU kernels handle those
-        maxabs = std::fmax(maxabs, std::fabs(static_cast<double>(h[k])));
-    }
-    if (maxabs == 0.0 || maxabs < 1e-30 || maxabs > 1e30) return FMRX_OK;
-    // largest s with max|round(h*2^s)| <= 127*256^(NDIG-1): every balanced digit then fits int8
-    const double limit = 127.0 * std::pow(256.0, kFeMfmaDigits - 1);
-    int s = static_cast<int>(std::floor(std::log2(limit / maxabs)));
-    while (std::ldexp(maxabs, s) > limit) s--;
+    int s = 0;
+    if (!fe_mfma_scale(h, taps, kFeMfmaDigits, &s)) return FMRX_OK;     // generic / vector-ALU kernels handle those taps
     std::vector<int8_t> img;
-#define X(T_, D_)                       \
-    if (taps == T_ && decim == D_) {    \
-        build_image<T_, D_>(h, s, img); \
-        pl.mfma = true;                 \
+#define X(T_, D_)                                                                          \
+    if (taps == T_ && decim == D_) {                                                       \
+        static_assert(MfCfg<T_, D_>::NDIG == kFeMfmaDigits, "digit count");                \
+        if (fe_mfma_shape(T_, D_).ksteps != MfCfg<T_, D_>::KSTEPS || fe_mfma_shape(T_, D_).front != MfCfg<T_, D_>::FRONT) \
+            return fail(FMRX_EINVAL, "fe_mfma: host and device tile shapes disagree");     \
+        fe_mfma_build_image(h, T_, D_, s, kFeMfmaDigits, img);                             \
+        pl.mfma = true;                                                                    \
     }
     FMRX_FE_MFMA_CASES(X)
 #undef X
@@ -748,14 +718,8 @@ int fe_mfma_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, cons
 // consecutive samples), i.e. h[decim*i + taps-1 - w], or 0 outside the filter.
 int audio_mfma_table_init(AudioPlan &pl, const float *h, int taps, int decim)
 {
-    const int awin = (taps - 1) + 15 * decim + 1, ak = (awin + 15) / 16 * 4;
-    std::vector<float> tab(static_cast<size_t>(ak) * 64, 0.0f);
-    for (int j = 0; j < ak; j++)
-        for (int lane = 0; lane < 64; lane++) {
-            const int w = 16 * (j / 4) + 4 * (lane >> 4) + j % 4;   // window sample of (K-step j, K index lane>>4)
-            const int k = decim * (lane & 15) + taps - 1 - w;
-            if (k >= 0 && k < taps) tab[j * 64 + lane] = h[k];
-        }
+    std::vector<float> tab;
+    audio_mfma_build_table(h, taps, decim, tab);
     FMRX_TRY(pl.mfma_table.alloc(tab.size()));
     FMRX_HIP(hipMemcpy(pl.mfma_table.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
     return FMRX_OK;

@@ -109,3 +109,27 @@ def test_cli_usage_and_modes(fmrx):
     if no_gpu(fmrx):
         r = subprocess.run([exe, "0", "1"], input=b"", capture_output=True)
         assert r.returncode == 2 and b"no usable HIP device" in r.stderr and r.stdout == b""
+
+
+@pytest.mark.parametrize("T,D,TA,DA", [(101, 10, 101, 5), (151, 10, 101, 5), (13, 10, 13, 5), (101, 5, 101, 6), (151, 5, 13, 6),
+                                       (13, 3, 101, 5), (101, 3, 13, 6), (151, 3, 101, 6)])
+def test_matrix_core_operands_host_side(fmrx, tmp_path, T, D, TA, DA):
+    """The operands the matrix-core kernels are fed are built on the host (csrc/fe_mfma_host.hpp):
+    24-bit fixed-point taps as three int8 digits in MFMA A-operand order, and the Toeplitz image of
+    the audio taps.  A g++-built emulation of the MFMAs' dot products (tests/cpp/fe_mfma_host_test.cpp)
+    must reproduce the FIR: digits exact, int32 accumulators in range, tile output within float32
+    rounding of the double-precision FIR; audio image exact.  No GPU involved."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "fe_mfma_host_test"
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(root, "software-defined-radio_amd", "csrc"), "-o", str(exe),
+                        os.path.join(root, "tests", "cpp", "fe_mfma_host_test.cpp")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rf_Fs = {10: 2.4e6, 5: 1.44e6, 3: 960e3}[D]
+    fmrx.impulseResponseLPF(rf_Fs, 100e3, T).astype(np.float32).tofile(tmp_path / "h.f32")
+    fmrx.impulseResponseLPF(rf_Fs / D, 16e3, TA).astype(np.float32).tofile(tmp_path / "ha.f32")
+    r = subprocess.run([str(exe), str(tmp_path / "h.f32"), str(T), str(D), str(tmp_path / "ha.f32"), str(TA), str(DA)],
+                       capture_output=True, text=True)
+    print(r.stdout)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
+
