@@ -81,28 +81,27 @@ __device__ __forceinline__ void wait_vmcnt()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// LDS-DMA of one tile's window (TILE_WIN bytes from STRIDE_BYTES*tile - LEAD of the block) into ring
-// slot rs.  Bytes before the block come from the tail of the history; addresses past the block are
-// clamped to its last 16 bytes (what lands there only ever meets zero taps or outputs that are not
-// stored), so every instruction is issued with its full, compile-time set of lanes: the counted
-// waits below depend on that.
-template <class C, int AUX = 0>
-__device__ __forceinline__ void mf_dma_tile(const uint8_t *__restrict__ x, const uint8_t *__restrict__ hist_end, long n_bytes,
-                                            int tile, uint8_t *ring, int rs, int lane)
+// LDS-DMA of NP * 1 KiB (the last piece REM_LANES lanes wide if not full) from byte offset s0 of the block
+// to dst (wave-uniform LDS address).  Bytes before the block come from the tail of the history; addresses past
+// the block are clamped to its last 16 bytes (what lands there only ever meets zero taps or outputs that are not
+// stored), so every instruction is issued with its full, compile-time set of lanes: the counted waits of the
+// kernels depend on that.  AUX = 2: non-temporal.
+template <int NPF, int REM_LANES, int AUX = 0>
+__device__ __forceinline__ void dma_window(const uint8_t *__restrict__ x, const uint8_t *__restrict__ hist_end, long n_bytes,
+                                           long s0, uint8_t *dst, int lane)
 {
-    const long s0 = static_cast<long>(tile) * C::STRIDE_BYTES - C::LEAD;   // wave-uniform
-    uint8_t *dst = ring + rs * C::SLOT;
-    if (s0 >= 0 && s0 + C::NP * 1024L <= n_bytes) {
+    constexpr int NP = NPF + (REM_LANES ? 1 : 0);
+    if (s0 >= 0 && s0 + NP * 1024L <= n_bytes) {
         const uint8_t *base = x + s0;   // scalar base, lane*16 + k*1024 offsets
 #pragma unroll
-        for (int k = 0; k < C::NP; k++)
-            if (k < C::NPF || lane < C::REM_LANES)
+        for (int k = 0; k < NP; k++)
+            if (k < NPF || lane < REM_LANES)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + (lane * 16 + k * 1024)),
                                                  (__attribute__((address_space(3))) void *)(dst + k * 1024), 16, 0, AUX);
     } else {
 #pragma unroll
-        for (int k = 0; k < C::NP; k++)
-            if (k < C::NPF || lane < C::REM_LANES) {
+        for (int k = 0; k < NP; k++)
+            if (k < NPF || lane < REM_LANES) {
                 long off = s0 + k * 1024 + lane * 16;
                 if (off > n_bytes - 16) off = n_bytes - 16;
                 const uint8_t *src = off < 0 ? hist_end + off : x + off;
@@ -110,6 +109,15 @@ __device__ __forceinline__ void mf_dma_tile(const uint8_t *__restrict__ x, const
                                                  (__attribute__((address_space(3))) void *)(dst + k * 1024), 16, 0, AUX);
             }
     }
+}
+
+// one tile's window of the S2/S1 kernel: TILE_WIN bytes from STRIDE_BYTES*tile - LEAD of the block into ring slot rs
+template <class C, int AUX = 0>
+__device__ __forceinline__ void mf_dma_tile(const uint8_t *__restrict__ x, const uint8_t *__restrict__ hist_end, long n_bytes,
+                                            int tile, uint8_t *ring, int rs, int lane)
+{
+    dma_window<C::NPF, C::REM_LANES, AUX>(x, hist_end, n_bytes, static_cast<long>(tile) * C::STRIDE_BYTES - C::LEAD,
+                                          ring + rs * C::SLOT, lane);
 }
 
 // DBG (tuning variants behind FMRX_FE_MFMA_TUNE, never dispatched by default):
@@ -331,30 +339,13 @@ struct FuCfg {
     static constexpr int LDS_WAVE = RING + (DR + MIRROR) * 4;
 };
 
+// tile slot u of the fused kernel: bytes [u*TILE - FRONT, (u+1)*TILE - FRONT) of the block into ring slot rs
 template <class C, class F>
 __device__ __forceinline__ void fu_dma_slot(const uint8_t *__restrict__ x, const uint8_t *__restrict__ hist_end, long n_bytes,
                                             int u, uint8_t *ring, int rs, int lane)
 {
-    const long s0 = static_cast<long>(u) * C::TILE_BYTES - F::FRONT;   // wave-uniform
-    uint8_t *dst = ring + rs * C::TILE_BYTES;
-    if (s0 >= 0 && s0 + C::NP * 1024L <= n_bytes) {
-        const uint8_t *base = x + s0;
-#pragma unroll
-        for (int k = 0; k < C::NP; k++)
-            if (k < C::NPF || lane < C::REM_LANES)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + (lane * 16 + k * 1024)),
-                                                 (__attribute__((address_space(3))) void *)(dst + k * 1024), 16, 0, 0);
-    } else {
-#pragma unroll
-        for (int k = 0; k < C::NP; k++)
-            if (k < C::NPF || lane < C::REM_LANES) {
-                long off = s0 + k * 1024 + lane * 16;
-                if (off > n_bytes - 16) off = n_bytes - 16;
-                const uint8_t *src = off < 0 ? hist_end + off : x + off;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(dst + k * 1024), 16, 0, 0);
-            }
-    }
+    dma_window<C::NPF, C::REM_LANES>(x, hist_end, n_bytes, static_cast<long>(u) * C::TILE_BYTES - F::FRONT,
+                                     ring + rs * C::TILE_BYTES, lane);
 }
 
 // PF / DRF / KPTF override P / DR / KPT, DBG compiles parts out -- ablation variants behind FMRX_FUSED_TUNE
