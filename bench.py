@@ -1,26 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the FM-receiver hot path on MI355X.
 
-Metric (BASELINE.json): complex I/Q mega-samples per second through the
-receiver chain, per job (all GPUs), and the dominant kernel's fraction of the
-HBM roofline.
+Metric (BASELINE.json): complex I/Q mega-samples per second through the receiver chain, per job (all
+GPUs), and the dominant kernel's fraction of the HBM roofline.
 
-Workload at N=1 = BASELINE.json configs[1]: mode 0 mono, 101-tap front-end
-FIR + decimate(10) + FM discriminator + 101-tap audio FIR + decimate(5) + s16
-pack, synthetic 2.4 MS/s FM I/Q, blocks of 1,024,000 complex samples.  One
-"step" = one pass of the whole chain over a device-resident batch of
-`--blocks` (default 256) consecutive blocks of one stream (0.5 GB of u8 I/Q),
-submitted as one block-parallel call (the mono chain is a sliding-window map of
-its input, SURVEY A.4, so this equals block-by-block streaming: bit for bit in the
-IF / discriminator stages and the carried state, to float32 summation order
-(<= 2e-6) in the audio FIR of the fused kernel --
-tests/test_gpu_parity.py::test_fused_mono_kernel, ::test_block_split_invariance_on_device).  Inputs are
-resident in HBM when the timed region starts; outputs (f32 audio + s16 PCM) are
-written to HBM.  N>1: one process per GPU, one independent channel per GPU
-(seed + rank), no data-path collective (RCCL is used only for the barrier and
-the max-over-ranks of the elapsed time): weak scaling.
+Workload at N=1 = BASELINE.json configs[1]: mode 0 mono, 101-tap front-end FIR + decimate(10) + FM
+discriminator + 101-tap audio FIR + decimate(5) + s16 pack (the reference's output format,
+src/threadMonoOnly.cpp:185-191), synthetic 2.4 MS/s FM I/Q, blocks of 1,024,000 complex samples.  One
+"step" = one pass of the whole chain over a device-resident batch of `--blocks` (default 256)
+consecutive blocks of ONE stream (0.5 GB of u8 I/Q), submitted as one block-parallel call: an offline,
+one-long-stream figure (a live 2.4 MS/s channel delivers 51,200-sample blocks; the per-block latency of
+that regime is reported separately as `small_block`).  The mono chain is a sliding-window map of its
+input, so the block-parallel call equals block-by-block streaming
+(tests/test_gpu_parity.py::test_fused_mono_kernel, ::test_block_split_invariance_on_device).  Inputs are
+resident in HBM when the timed region starts; the s16 PCM is written to HBM.
 
-Prints ONE JSON line (rank 0).
+N>1: one process per GPU, one independent channel per GPU (seed + rank), no data-path collective: weak
+scaling.  `python bench.py --gpus N` starts the N ranks itself (child processes, control plane over
+gloo: the north star leaves RCCL unused); under `torch.distributed.run` (RANK / WORLD_SIZE set) it is
+one of the ranks.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -28,10 +26,10 @@ import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "tests")):
@@ -39,23 +37,27 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 BLOCK_SAMPLES = 1_024_000          # complex samples per block (= 20 reference blocks)
-PROF_EVERY = 4                     # HIP events around every 4th launch of the timed region
 HBM_PEAK_GBS = 8000.0              # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-# algorithmic HBM bytes per complex input sample of the dominant kernel = the whole mono chain
-# fused (S3): 2 B of u8 I/Q in + (4 B f32 audio + 2 B s16 PCM) per rf_decim*audio_decim
-# = 50 input samples out.  (SURVEY's S3 figures are 2.04 B for s16 only, 2.08 B for f32 only; this
-# workload writes both.)  S2 (front end + discriminator to HBM) would be 2.4 B, S1 (IF only) 2.8 B.
-FE_BYTES_PER_SAMPLE = 2.0 + (4.0 + 2.0) / 50.0
+# Algorithmic HBM bytes per complex input sample:
+S3_BYTES = 2.0 + 2.0 / 50.0        # whole mono chain fused, s16 out: 2 B of u8 I/Q in + 2 B per rf_decim*audio_decim = 50 samples
+S2_BYTES = 2.0 + 4.0 / 10.0        # front end + discriminator to HBM (f32 demod out)
+S1_BYTES = 2.0 + 8.0 / 10.0        # front end only: f32 IF I,Q out
 FE_FLOP_PER_SAMPLE = 2 * 2 * 101 / 10.0 + 9 / 10.0 + 2 * 101 / 50.0     # useful FIR + discriminator flops
 
 
+# ------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle = the reference's algorithm restated; checker library, this leg only)
+# ------------------------------------------------------------------------------------------------
 def cpu_baseline(seconds: float = 10.0) -> dict:
-    """The oracle (C restatement of the reference, oracle/fm_oracle.c, -O3 like
-    src/Makefile:4) timed on this host: same chain, same taps, same signal.
-    Single thread = the reference-equivalent figure; then one independent
+    """oracle/fm_oracle.c (-O3 like src/Makefile:4) timed on this host: same chain, same taps, same
+    signal.  (i) single thread = the figure to quote; (ii) the reference's own 2-thread shape
+    (src/project.cpp:470-496: front-end thread -> 6-deep queue -> audio thread); (iii) one independent
     channel per available core."""
+    import queue
+    import threading
     from concurrent.futures import ThreadPoolExecutor
 
+    import numpy as np
     from _oracle import Oracle  # checker library: allowed here (cpu_baseline leg) only
     synth = importlib.import_module("software-defined-radio_amd.synth")
     o = Oracle()
@@ -75,26 +77,65 @@ def cpu_baseline(seconds: float = 10.0) -> dict:
                 break
         return done, time.perf_counter() - t0
 
+    def run_two_threads(budget_s: float) -> tuple[int, float]:
+        h_rf, h_au = o.impulse_response_lpf(2.4e6, 100e3, 101), o.impulse_response_lpf(240e3, 16e3, 101)
+        q: queue.Queue = queue.Queue(maxsize=6)           # QUEUE_ELEMS, include/dy4.h:30
+        done = [0]
+        t0 = time.perf_counter()
+
+        def front_end():
+            si = sq = np.zeros(100, np.float32)
+            pi = pq = 0.0
+            while time.perf_counter() - t0 < budget_s:
+                for b in range(nblk_ref):
+                    f = o.u8_to_f32(iq[b * 102400:(b + 1) * 102400])
+                    fi, si = o.convolve_block_fast_fir(f[0::2], h_rf, si, 10)
+                    fq, sq = o.convolve_block_fast_fir(f[1::2], h_rf, sq, 10)
+                    d, pi, pq = o.fm_demod(fi, fq, pi, pq)
+                    q.put(d)
+            q.put(None)
+
+        def audio():
+            st = np.zeros(100, np.float32)
+            while True:
+                d = q.get()
+                if d is None:
+                    return
+                y, st = o.convolve_block_fast_fir(d, h_au, st, 5)
+                o.pcm16(y)
+                done[0] += 51200
+
+        ta, tb = threading.Thread(target=front_end), threading.Thread(target=audio)
+        ta.start(); tb.start(); ta.join(); tb.join()
+        return done[0], time.perf_counter() - t0
+
     n1, t1 = run(seconds)
+    n2, t2 = run_two_threads(seconds * 0.3)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(cores, 64))
     with ThreadPoolExecutor(cores) as ex:                # ctypes releases the GIL inside the C call
         t0 = time.perf_counter()
-        res = list(ex.map(lambda c: run(seconds * 0.6, c + 1), range(cores)))
+        res = list(ex.map(lambda c: run(seconds * 0.5, c + 1), range(cores)))
         wall = time.perf_counter() - t0
     return {
         "value": round(n1 / t1 / 1e6, 2), "unit": "MS/s", "cores": 1, "kind": "port",
         "sample": f"mode-0 mono chain (101/101 taps), {n1} complex samples in {t1:.1f} s, single thread, "
                   "oracle/fm_oracle.c built -O3 (reference flags)",
+        "two_thread_pipeline": {"value": round(n2 / t2 / 1e6, 2), "unit": "MS/s", "cores": 2,
+                                "sample": f"front-end thread -> 6-deep queue -> audio thread (src/project.cpp:470-496), {t2:.1f} s; "
+                                          "stage calls through ctypes/numpy, so an upper bound on the reference binary's overhead"},
         "all_cores": {"value": round(sum(r[0] for r in res) / wall / 1e6, 2), "unit": "MS/s", "cores": cores,
                       "sample": f"{cores} independent channels, one per core, {wall:.1f} s"},
     }
 
 
+# ------------------------------------------------------------------------------------------------
+# ranks
+# ------------------------------------------------------------------------------------------------
 def init_ranks(backend: str | None):
-    """One process per GPU (torch.distributed.run sets RANK/LOCAL_RANK/WORLD_SIZE).
-    Returns (rank, local_rank, world, dist-or-None).  The process group is CONTROL
-    PLANE only (barrier + max of the elapsed time): channels never exchange data."""
+    """One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from the environment).  Returns
+    (rank, local_rank, world, dist-or-None).  The process group is CONTROL PLANE only (barrier + max of
+    the elapsed time): channels never exchange data."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -116,9 +157,10 @@ def channel_seed(rank: int) -> int:
     return 0x3D74 + rank
 
 
-def timed_region(step, sync, steps: int, warmup: int, dist, device=None) -> float:
+def timed_region(step, sync, steps: int, warmup: int, dist, device=None, on_start=None, on_stop=None) -> float:
     """W untimed warm-up steps, then exactly K steps bracketed by barrier + device sync on both
-    sides; returns the MAX over ranks of the elapsed seconds."""
+    sides; returns the MAX over ranks of the elapsed seconds.  on_start / on_stop: hooks inside the
+    bracket (device events on the launch stream)."""
     import torch
 
     def barrier():
@@ -131,8 +173,12 @@ def timed_region(step, sync, steps: int, warmup: int, dist, device=None) -> floa
         step()
     barrier()
     t0 = time.perf_counter()
+    if on_start:
+        on_start()
     for _ in range(steps):
         step()
+    if on_stop:
+        on_stop()
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -147,6 +193,174 @@ def job_throughput(world: int, samples_per_step_per_rank: int, steps: int, elaps
     return world * samples_per_step_per_rank * steps / elapsed_max / 1e6
 
 
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n: int, argv: list[str]) -> int:
+    """`bench.py --gpus N` without a launcher: start N child processes of this script, one rank per GPU
+    (LOCAL_RANK = device ordinal), rendezvous on 127.0.0.1, and relay rank 0's JSON line.  The parent
+    never touches the GPU (children are started, not exec'ed into)."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    line = next((l for l in reversed((out0 or "").splitlines()) if l.startswith("{")), None)
+    if line:
+        print(line, flush=True)
+    if any(rcs) or not line:
+        sys.stderr.write(f"bench.py: ranks exited with {rcs}\n")
+        return next((rc for rc in rcs if rc), 1)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------
+# device-side measurement helpers
+# ------------------------------------------------------------------------------------------------
+def event_ms(torch, step, k: int, warm: int = 3) -> float:
+    """Average device time of one step: HIP events on the launch stream (torch's current stream, the one
+    every step is submitted to) around k back-to-back steps.  Includes the dispatch gap between
+    consecutive kernels (1-2 us), subtracts nothing."""
+    for _ in range(warm):
+        step()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(k):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / k
+
+
+def leg(name, what, n_samples, ms, bytes_per_sample, extra=None):
+    gbs = bytes_per_sample * n_samples / (ms * 1e-3) / 1e9
+    d = {"what": what, "samples_per_step": n_samples, "ms_per_step": round(ms, 4), "value": round(n_samples / (ms * 1e-3) / 1e6, 1),
+         "unit": "MS/s", "algorithmic_bytes_per_sample": round(bytes_per_sample, 3), "achieved_GBs": round(gbs, 1),
+         "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    if extra:
+        d.update(extra)
+    return name, d
+
+
+def side_legs(torch, fmrx, synth, args, pl, step, d_iq, n_bytes, stream) -> dict:
+    """N=1 only, after the timed region: the other configurations and kernels of the path, each with its
+    algorithmic bytes per sample, device time per step and fraction of the HBM peak."""
+    legs = {}
+    n_samples = n_bytes // 2
+    k = max(10, min(args.steps, 30))
+    # (1) the same workload through the vector-ALU kernels: the north star's "no MFMA" form (S2 + audio kernel)
+    pl.set_option("fe_variant", "valu")
+    ms = event_ms(torch, step, k, warm=100)
+    pl.set_profiling(4)
+    for _ in range(16):
+        step()
+    torch.cuda.synchronize()
+    t4, c4 = pl.timing_sum(4)
+    pl.set_profiling(False)
+    fe_ms = max(ms - t4["audio_ms"] / c4, 1e-6)
+    legs["north_star_form"] = {
+        "fe_variant": "valu", "value": round(n_samples / (ms * 1e-3) / 1e6, 1), "unit": "MS/s", "ms_per_step": round(ms, 4),
+        "kernel": "fe_demod_kernel<101,10,8> (v_pk_fma_f32 FIR + discriminator, S2: 2.4 B/sample) then audio_fir_kernel",
+        "avg_launch_ms": round(fe_ms, 4), "achieved": round(S2_BYTES * n_samples / (fe_ms * 1e-3) / 1e9, 1),
+        "frac": round(S2_BYTES * n_samples / (fe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "steps": k,
+        "note": "avg_launch_ms = step time minus the audio kernel's event-bracketed time"}
+    pl.set_option("fe_variant", "mfma")
+    # (2) S2: matrix-core front end + discriminator to HBM, then the audio kernel (the two-kernel path)
+    pl.set_option("fused_min_audio", 10**12)
+    ms = event_ms(torch, step, k)
+    name, d = leg("two_kernel_path", "fe_mfma_kernel<101,10> (S2, f32 demod to HBM) + audio_fir_kernel, mode 0 mono", n_samples, ms,
+                  S2_BYTES + 4.0 / 10.0 + 2.0 / 50.0)
+    legs[name] = d
+    pl.set_option("fused_min_audio", 65536)
+    # (3) S1: the north star's literal kernel, IF only (u8 I/Q -> f32 IF I,Q)
+    h = fmrx.impulseResponseLPF(2.4e6, 100e3, 101)
+    plan = fmrx.FrontEndPlan(h, 10)
+    d_if = torch.empty(2 * (n_samples // 10), dtype=torch.float32, device="cuda")
+    for var in ("mfma", "valu"):
+        fmrx.set_option("fe_variant", var)
+        ms = event_ms(torch, lambda: plan.run_dev(d_iq.data_ptr(), n_samples, None, d_if.data_ptr(), stream=stream), k,
+                      warm=100 if var == "valu" else 3)
+        name, d = leg(f"s1_if_only_{var}", f"front-end FIR + decimate only (S1), {var} kernel, fmrx_fe_run_dev", n_samples, ms, S1_BYTES)
+        legs[name] = d
+    fmrx.set_option("fe_variant", "mfma")
+    del d_if, plan
+    # (4) the other modes / stereo, streaming (state carried), device-resident
+    def mode_leg(name, mode, channels, blocks, what, bytes_per_sample, bytes_unit, base_blocks=1):
+        # base_blocks blocks are synthesised and repeated; stereo needs a seamless stream (a splice is a pilot phase
+        # jump: the PLL would un-lock and be repaired): 3 x 1,024,000 samples = 1280 periods of the 1 ms multiplex
+        p = fmrx.modeParams(mode)
+        nb = blocks * bytes_unit
+        iq = synth.synth_fm_u8(base_blocks * bytes_unit // 2, float(p.rf_Fs), seed=0x3D74 + 10 + mode)
+        d_in = torch.from_numpy(iq).cuda().repeat(blocks // base_blocks)
+        q = fmrx.Pipeline(mode, channels, max_block_bytes=nb, device=torch.cuda.current_device())
+        na = q.n_audio(nb)
+        d_pcm = torch.empty(channels * na, dtype=torch.int16, device="cuda")
+        fn = lambda: q.process_dev(d_in.data_ptr(), nb, None, d_pcm.data_ptr(), wrap=True, stream=stream)
+        ms = event_ms(torch, fn, k, warm=5)
+        nm, d = leg(name, what, nb // 2, ms, bytes_per_sample)
+        if channels == 2:
+            d["pll_repaired_segments"] = q.pll_diagnostics()[0]
+        legs[nm] = d
+        q.close()
+
+    mode_leg("mode1_mono", 1, 1, 64, "mode 1 mono (1.44 MS/s, decim 5 x 6), fused kernel, 64 x 1,024,000-sample blocks", 2.0 + 2.0 / 30.0, 2048000)
+    mode_leg("mode2_mono", 2, 1, 63, "mode 2 mono (U/D = 147/800 resampler), 63 blocks of 1,008,000 samples", 2.0 + 2.0 * 147 / 8000.0, 2016000)
+    mode_leg("mode3_mono", 3, 1, 63, "mode 3 mono (960 kS/s, U/D = 441/3200), 63 blocks of 1,008,000 samples", 2.0 + 2.0 * 441 / 9600.0, 2016000)
+    mode_leg("mode0_stereo", 0, 2, 12, "mode 0 stereo (pilot PLL + 38 kHz mixer + L/R), s16 L,R out, 12 x 1,024,000-sample blocks per step, stream continued",
+             2.0 + 4.0 / 50.0, 2048000, base_blocks=3)
+    # (5) a live channel's regime: reference-size blocks (51,200 samples), one call per block, device-resident
+    q = fmrx.Pipeline(0, 1, device=torch.cuda.current_device())
+    d_pcm = torch.empty(1024, dtype=torch.int16, device="cuda")
+    ms = event_ms(torch, lambda: q.process_dev(d_iq.data_ptr(), 102400, None, d_pcm.data_ptr(), wrap=True, stream=stream), 200, warm=20)
+    legs["small_block"] = {"what": "mode 0 mono, one 51,200-sample reference block per call (what a live 2.4 MS/s channel delivers)",
+                           "us_per_block": round(ms * 1e3, 2), "x_real_time": round(51200 / 2.4e6 / (ms * 1e-3), 1)}
+    q.close()
+    # (6) what this box's memory system gives a pure streaming read, by the access methods the kernels use
+    reads = {}
+    for method, label in ((0, "global_load_dwordx4 non-temporal to registers"), (1, "LDS-DMA ring (the matrix-core kernels' method)")):
+        try:
+            ms = event_ms(torch, lambda: fmrx.diagStreamRead(d_iq.data_ptr(), n_bytes, method, stream), 20, warm=20)
+            reads[label] = round(n_bytes / (ms * 1e-3) / 1e9, 1)
+        except Exception as e:  # diagnostics only
+            reads[label] = f"unavailable: {e}"
+    src = torch.empty(128 * 1024 * 1024, dtype=torch.float32, device="cuda").normal_()
+    dst = torch.empty_like(src)
+    ms = event_ms(torch, lambda: dst.copy_(src), 20, warm=5)
+    reads["torch d2d copy of 512 MiB, bytes read + written"] = round(2 * src.numel() * 4 / (ms * 1e-3) / 1e9, 1)
+    del src, dst
+    legs["measured_streaming_GBs"] = reads
+    return legs
+
+
+def run_stub(args) -> int:
+    """Test hook (tests/test_multiproc_cpu.py): the launcher, the rank environment and the timing /
+    aggregation logic without a GPU -- a step is a sleep of stub_ms * (rank + 1)."""
+    rank, local_rank, world, dist = init_ranks("gloo")
+    if world != args.gpus:
+        print(json.dumps({"error": f"WORLD_SIZE {world} != --gpus {args.gpus}"}))
+        return 2
+    elapsed = timed_region(lambda: time.sleep(args.stub_ms * 1e-3 * (rank + 1)), lambda: None, args.steps, args.warmup, dist)
+    seeds = [channel_seed(rank)]
+    if dist is not None:
+        seeds = [None] * world
+        dist.all_gather_object(seeds, channel_seed(rank))
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": job_throughput(world, 1000, args.steps, elapsed), "unit": "MS/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "data": "stub",
+                          "seeds": seeds, "local_rank": local_rank}), flush=True)
+    return 0
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,31 +369,48 @@ def main() -> int:
     ap.add_argument("--blocks", type=int, default=256, help="1,024,000-sample blocks resident per step")
     ap.add_argument("--settle-ms", type=float, default=400.0,
                     help="untimed steps run for this long before the warm-up, so that the clocks the chip holds under "
-                         "this load are reached (a step is ~0.13 ms; the first ~300 after idle run up to 30 %% slower)")
+                         "this load are reached (a step is ~0.12 ms; the first ~300 after idle run up to 30 %% slower)")
     ap.add_argument("--fe-variant", default="mfma", choices=["mfma", "valu"],
                     help="mfma (default): matrix-core kernels, whole mono chain fused; valu: the vector-ALU kernels "
                          "(front end + discriminator, then the audio kernel) -- the 'no MFMA' form of the north star")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-legs", action="store_true", help="skip the N=1 side measurements (other modes, S1/S2 kernels, copy probe)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="control-plane backend for N>1 (nccl = RCCL; gloo only to rehearse N>1 on a one-GPU box)")
+    ap.add_argument("--dist-backend", default="gloo", choices=["gloo", "nccl"],
+                    help="control-plane backend for N>1 (barrier + max of the elapsed time only; gloo: RCCL stays unused as the north star says)")
     ap.add_argument("--all-on-device0", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--stub-ms", type=float, default=0.0, help=argparse.SUPPRESS)   # test hook: see run_stub
     args = ap.parse_args()
 
-    if args.fe_variant == "valu":
-        os.environ["FMRX_FE_VARIANT"] = "valu"     # read per call by libfmrx
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        print(json.dumps({"error": "--gpus must be >= 1"}))
+        return 2
+    if world_env is None and args.gpus > 1:
+        return spawn_ranks(args.gpus, sys.argv[1:])            # before anything touches the GPU
+    if world_env is not None and int(world_env) != args.gpus:
+        print(json.dumps({"error": f"WORLD_SIZE={world_env} but --gpus {args.gpus}: launch with --nproc-per-node {args.gpus}"}))
+        return 2
+    if args.stub_ms > 0:
+        return run_stub(args)
+
+    import numpy as np  # noqa: F401
     import torch
 
     if not torch.cuda.is_available():
         print(json.dumps({"error": "no GPU visible; libfmrx has no CPU fallback"}))
         return 2
     dev_index = 0 if args.all_on_device0 else int(os.environ.get("LOCAL_RANK", "0"))
+    if dev_index >= torch.cuda.device_count():
+        print(json.dumps({"error": f"rank needs GPU {dev_index} but only {torch.cuda.device_count()} visible (--gpus {args.gpus})"}))
+        return 3
     torch.cuda.set_device(dev_index)
     rank, local_rank, world, dist = init_ranks(args.dist_backend)
     local_rank = dev_index
 
     fmrx = importlib.import_module("software-defined-radio_amd")
     synth = importlib.import_module("software-defined-radio_amd.synth")
+    stray = sorted(k for k in os.environ if k.startswith("FMRX_") and k not in ("FMRX_LIB", "FMRX_NO_TORCH"))
 
     # ---- device-resident synthetic stream: this rank's channel ----
     B = args.blocks
@@ -189,13 +420,13 @@ def main() -> int:
     n_bytes = d_iq.numel()
     n_samples = n_bytes // 2
     pl = fmrx.Pipeline(0, 1, rf_taps=101, base_audio_taps=101, max_block_bytes=n_bytes, device=local_rank)
+    pl.set_option("fe_variant", args.fe_variant)
     n_audio = pl.n_audio(n_bytes)
-    d_audio = torch.empty(n_audio, dtype=torch.float32, device="cuda")
     d_pcm = torch.empty(n_audio, dtype=torch.int16, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        pl.process_dev(d_iq.data_ptr(), n_bytes, d_audio.data_ptr(), d_pcm.data_ptr(), wrap=True, stream=stream)
+        pl.process_dev(d_iq.data_ptr(), n_bytes, None, d_pcm.data_ptr(), wrap=True, stream=stream)
 
     # untimed: bring the device from idle to the clocks it sustains under this load, then W warm-up steps
     t_settle = time.perf_counter()
@@ -203,79 +434,42 @@ def main() -> int:
         for _ in range(20):
             step()
         torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    # HIP events around the dominant kernel, on the launch stream, every PROF_EVERY-th step of the timed
-    # region (an event record costs ~5 us of stream time, 4 % of a step)
-    pl.set_profiling(PROF_EVERY)
-    elapsed = timed_region(step, torch.cuda.synchronize, args.steps, 0, dist,
-                           device="cuda" if args.dist_backend == "nccl" else "cpu")
-
-    tsum, cnt = pl.timing_sum((args.steps + PROF_EVERY - 1) // PROF_EVERY)
-    # The fused kernel is the whole step: the handle's other two event pairs then bracket nothing and
-    # measure what a pair of event records itself takes on the stream (~4-5 us); the kernel's launch
-    # duration is the bracketed interval minus that (it then agrees with rocprofv3's kernel trace).
-    # (with --fe-variant valu the audio kernel sits in the second pair; the third is still empty.)
-    pair_ms = min(tsum["audio_ms"], tsum["rest_ms"]) / cnt
-    fused = args.fe_variant == "mfma" and tsum["audio_ms"] / cnt < 0.02
-    fe_ms = tsum["front_end_ms"] / cnt - pair_ms
-    pl.set_profiling(False)
-
-    # ---- side legs, after the timed region, N=1 only: (1) the same workload through the vector-ALU
-    #      kernels (the north star's "no MFMA" form), (2) what a plain device-to-device copy reaches on
-    #      this box (report the fraction of measured copy bandwidth next to the 8 TB/s peak) ----
-    north_star_form = copy_gbs = None
-    if world == 1 and args.fe_variant == "mfma":
-        os.environ["FMRX_FE_VARIANT"] = "valu"
-        for _ in range(200):
+    # HIP events on the launch stream bracket exactly the K timed launches (recorded inside the barrier
+    # bracket): average launch duration of the dominant kernel = bracket / K, dispatch gaps included
+    ev = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+    elapsed = timed_region(step, torch.cuda.synchronize, args.steps, args.warmup, dist,
+                           device="cuda" if args.dist_backend == "nccl" else "cpu",
+                           on_start=ev[0].record, on_stop=ev[1].record)
+    fe_ms = ev[0].elapsed_time(ev[1]) / args.steps
+    fused = args.fe_variant == "mfma"
+    if not fused:   # vector-ALU variant: the step is two kernels; the front end's share from the handle's event brackets
+        pl.set_profiling(4)
+        for _ in range(16):
             step()
         torch.cuda.synchronize()
-        pl.set_profiling(PROF_EVERY)
-        k2 = max(20, min(args.steps, 50))
-        t0 = time.perf_counter()
-        for _ in range(k2):
-            step()
-        torch.cuda.synchronize()
-        dt2 = time.perf_counter() - t0
-        t2, c2 = pl.timing_sum((k2 + PROF_EVERY - 1) // PROF_EVERY)
+        t4, c4 = pl.timing_sum(4)
         pl.set_profiling(False)
-        os.environ.pop("FMRX_FE_VARIANT")
-        fe2 = (t2["front_end_ms"] - t2["rest_ms"]) / c2
-        north_star_form = {
-            "fe_variant": "valu", "value": round(n_samples * k2 / dt2 / 1e6, 1), "unit": "MS/s",
-            "kernel": "fe_demod_kernel<101,10,8> (v_pk_fma_f32 FIR + discriminator, S2: 2.4 B/sample) then audio_fir_kernel",
-            "avg_launch_ms": round(fe2, 4), "achieved": round(2.4 * n_samples / (fe2 * 1e-3) / 1e9, 1),
-            "frac": round(2.4 * n_samples / (fe2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "steps": k2,
-        }
-    if world == 1:
-        src = torch.empty(128 * 1024 * 1024, dtype=torch.float32, device="cuda").normal_()
-        dst = torch.empty_like(src)
-        for _ in range(5):
-            dst.copy_(src)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(20):
-            dst.copy_(src)
-        e1.record()
-        torch.cuda.synchronize()
-        copy_gbs = 2 * src.numel() * 4 * 20 / (e0.elapsed_time(e1) * 1e-3) / 1e9     # bytes read + written
-        del src, dst
+        fe_ms = max(fe_ms - t4["audio_ms"] / c4, 1e-6)
+
+    legs = {}
+    if world == 1 and fused and not args.no_side_legs:
+        legs = side_legs(torch, fmrx, synth, args, pl, step, d_iq, n_bytes, stream)
 
     out = None
     if rank == 0:
         value = job_throughput(world, n_samples, args.steps, elapsed)
-        # dominant kernel: the fused mono kernel (S3: 2.12 B/sample) or, for --fe-variant valu, the
-        # vector-ALU front end + discriminator (S2: 2 B in + 4/10 B of f32 demod out)
-        bytes_per_sample = FE_BYTES_PER_SAMPLE if fused else 2.0 + 4.0 / 10.0
+        bytes_per_sample = S3_BYTES if fused else S2_BYTES
         fe_bytes = bytes_per_sample * n_samples
         achieved = fe_bytes / (fe_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "fe_traffic.json")   # PMC-derived bytes per launch, if collected
-        if os.path.exists(tpath):
+        traffic, traffic_source = None, None
+        tpath = os.path.join(ROOT, "profiles", "fe_traffic.json")   # PMC-derived bytes per launch of this command
+        if fused and os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if int(tj.get("blocks", -1)) == B:
+                if int(tj.get("blocks", -1)) == B and tj.get("output") == "s16":
                     traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_source = ("profiles/fe_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                                      f"({tj.get('round', 'earlier round')}); a committed constant, NOT measured in this run")
             except Exception:
                 traffic = None
         out = {
@@ -285,29 +479,36 @@ def main() -> int:
             "vs_baseline": None, "dtype": "i8+f32" if fused else "f32", "data": "synthetic",
             "config": {
                 "workload": "configs[1]: mode 0 mono, 101-tap FE FIR+decimate(10) + FM discriminator + 101-tap audio "
-                            "FIR+decimate(5) + s16 pack; synthetic 2.4 MS/s FM I/Q (u8), 1,024,000-sample blocks",
+                            "FIR+decimate(5) + s16 pack; synthetic 2.4 MS/s FM I/Q (u8), 1,024,000-sample blocks; "
+                            "offline: one long stream per GPU, all blocks of a step in one block-parallel call",
                 "blocks_per_step": B, "samples_per_step_per_gpu": n_samples,
-                "sharding": f"{world} independent channel(s), one per GPU, no collective",
-                "realtime_channels_equiv": round(value / 2.4, 0), "settle_ms": args.settle_ms,
+                "sharding": f"{world} independent channel(s), one per GPU, no collective (control plane: {args.dist_backend})",
+                "settle_ms": args.settle_ms, "fmrx_env": stray,
             },
             "roofline": {
                 "kernel": ("mono_fused_kernel<101,10,101,5> (u8 I/Q -> 101-tap FIR, decimate 10 (int8 MFMA) -> FM "
-                           "discriminator -> 101-tap audio FIR, decimate 5 (f32 MFMA) -> f32 audio + s16 PCM)") if fused else
+                           "discriminator -> 101-tap audio FIR, decimate 5 (f32 MFMA) -> s16 PCM)") if fused else
                           "fe_demod_kernel<101,10,8> (u8 I/Q -> 101-tap FIR, decimate 10 (v_pk_fma_f32) -> FM discriminator -> f32 demod)",
-                "algorithmic_bytes_per_sample": round(bytes_per_sample, 2), "fe_variant": args.fe_variant,
+                "algorithmic_bytes_per_sample": round(bytes_per_sample, 3),
+                "algorithmic_bytes_note": "SURVEY 8d S3 (whole mono chain, s16 out: 2 + 2/50)" if fused else "SURVEY 8d S2 (2 + 4/10)",
+                "fe_variant": args.fe_variant,
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic if fused else None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": int(fe_bytes), "avg_launch_ms": round(fe_ms, 4),
-                "launches_timed": cnt, "event_pair_overhead_ms": round(pair_ms, 4),
+                "launches_timed": args.steps,
+                "timing": "HIP events on the launch stream around the K timed launches / K (dispatch gaps included, nothing subtracted)",
                 "useful_tflops": round(FE_FLOP_PER_SAMPLE * n_samples / (fe_ms * 1e-3) / 1e12, 2),
-                "stage_ms": {k: round(v / cnt, 4) for k, v in tsum.items()},
-                "measured_copy": None if copy_gbs is None else {
-                    "what": "torch d2d copy of 512 MiB f32, bytes read + written per second", "GB/s": round(copy_gbs, 1),
-                    "frac_of_copy": round(achieved / copy_gbs, 4)},
             },
         }
-        if north_star_form is not None:
-            out["north_star_form"] = north_star_form
+        if legs:
+            out["north_star_form"] = legs.pop("north_star_form")
+            reads = legs.pop("measured_streaming_GBs", None)
+            if reads:
+                out["roofline"]["measured_streaming_GBs"] = reads
+                best = max((v for v in reads.values() if isinstance(v, (int, float))), default=None)
+                if best:
+                    out["roofline"]["frac_of_best_measured_streaming"] = round(achieved / best, 4)
+            out["legs"] = legs
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
     if dist is not None:

@@ -65,6 +65,23 @@ FMRX_API int fmrx_device_count(void);
 /* select the device used by the host-pointer stage functions of this thread */
 FMRX_API int fmrx_set_device(int device);
 
+/* Run-time options (tuning and A/B knobs; none is needed in normal use).  The process-wide defaults are
+ * the built-in values, overridden ONCE, when the library first needs them, by the environment variable
+ * FMRX_<NAME IN CAPITALS>; fmrx_set_option changes the defaults afterwards.  A pipeline handle copies the
+ * defaults when it is created and keeps its own set (fmrx_pipeline_set_option); the stage functions use the
+ * defaults.  Nothing on a per-block path reads the environment.
+ *   "fe_variant"       0 = matrix-core front-end kernels (default; FMRX_FE_VARIANT=mfma), 1 = vector-ALU kernels (=valu)
+ *   "fused_min_audio"  audio samples per call from which the fused mono kernel is used (default 65536; 0 = always)
+ *   "resample_l2"      1 = the L2-table resampler kernel also for large calls
+ *   "fe_wgs_per_cu"    cap on resident workgroups per CU of the front-end kernels (0 = auto)
+ *   "pll_warmup", "pll_segment", "pll_head"   lane shape of the parallel-in-time PLL (-1 = built-in)
+ *   "pll_mode"         stereo PLL of the specialised pipeline: 0 = parallel in time, fast math (default),
+ *                      1 = serial, fast math, 2 = serial, glibc's functions (cause-by-cause variants)
+ *   "fused_tune", "fe_mfma_tune"              ablation kernels (timing only, WRONG results): FMRX_EINVAL unless the
+ *                                            library was built with -DFMRX_TUNING (make TUNING=1; never shipped) */
+FMRX_API int fmrx_set_option(const char *name, long value);
+FMRX_API int fmrx_get_option(const char *name, long *value);
+
 /* page-locked host buffers for the block-streaming callers (faster, truly
  * asynchronous H2D/D2H); free with fmrx_host_free.  Plain malloc memory works
  * everywhere too. */
@@ -118,7 +135,10 @@ FMRX_API int fmrx_fm_demod(float *out, const float *I, const float *Q, size_t n,
  * requires n >= nstate. */
 FMRX_API int fmrx_all_pass(const float *in, size_t n, float *state, size_t nstate, float *out);
 /* replaces fmPLL  include/filter.h:22, src/filter.cpp:32-80.  nco_out[n+1];
- * state[6] = {integrator, phaseEst, feedbackI, feedbackQ, lastOut, trigOffset}. */
+ * state[6] = {integrator, phaseEst, feedbackI, feedbackQ, lastOut, trigOffset}.
+ * Serial recurrence with the reference's float32 operations in its order and the
+ * sinf / cosf / atan2f of its C library (glibc 2.35, restated in
+ * csrc/glibc_libm.hpp and pinned against it): bit-identical to the reference. */
 FMRX_API int fmrx_fm_pll(const float *in, size_t n, float *nco_out, float *state, float freq, float Fs,
                          float ncoScale, float phaseAdjust, float normBandwidth);
 /* replaces the mixer and L/R combine loops  src/project.cpp:246-248, 277-280 */
@@ -132,6 +152,15 @@ FMRX_API int fmrx_pcm16(const float *audio, size_t n, int16_t *out, int wrap);
 /* ------------------------------------------------------------------ */
 /* diagnostics                                                          */
 /* ------------------------------------------------------------------ */
+/* out[i] = sinf(a[i]) (fn 0), cosf(a[i]) (fn 1) or atan2f(a[i], b[i]) (fn 2) as the DEVICE evaluates the
+ * restatement of glibc 2.35's functions that fmPLL uses (csrc/glibc_libm.hpp): lets a test compare the
+ * device build with the C library of the host, bit for bit.  b may be NULL for fn 0, 1. */
+FMRX_API int fmrx_diag_libm(int fn, const float *a, const float *b, size_t n, float *out);
+/* Measurement aid for bench.py: ONE pure streaming read of a device buffer (>= 3 MiB, 16-byte aligned) by
+ * one of the access methods the front-end kernels use -- method 0: non-temporal global loads into
+ * registers, 1: LDS-DMA ring -- asynchronous on `stream`; the caller times it (what the memory system gives
+ * a read-only kernel, next to the nominal 8 TB/s). */
+FMRX_API int fmrx_diag_stream_read_dev(const void *d_buf, size_t bytes, int method, void *stream);
 /* replaces estimatePSD  include/fourier.h, src/fourier.cpp:44-128 (with its DFT,
  * :15-23): Bartlett average, in dB, of Hann-windowed nfft-point spectra of
  * `samples`; the reference fixes nfft = NFFT = 512 (include/dy4.h:27).
@@ -231,15 +260,22 @@ FMRX_API int fmrx_pipeline_set_profiling(fmrx_pipeline *pl, int on);
  * after a process call (diagnostics and tests; default 0; read_tap returns
  * FMRX_EINVAL for a tap that was not stored). */
 FMRX_API int fmrx_pipeline_set_keep_intermediates(fmrx_pipeline *pl, int on);
-/* Stereo only.  The pilot PLL (fmPLL, src/filter.cpp:32-80) runs parallel in time
- * (segments with warm-up, verified against the neighbouring segment, serial repair
- * where the loop was not locked).  Cumulative since creation: segments that had to
+/* Stereo only.  In the specialised pipeline the pilot PLL (fmPLL, src/filter.cpp:32-80) runs parallel
+ * in time (segments with warm-up, checked against the neighbouring segment within a tolerance, serial
+ * repair where the loop was not locked); it agrees with the serial recurrence to within the float32
+ * grid of its phase argument, not bit for bit (see set_force_generic for the bit-exact mode).  Cumulative since creation: segments that had to
  * be re-run serially, and the largest phase / integrator difference accepted as
  * "merged" at a segment boundary. */
 FMRX_API int fmrx_pipeline_pll_diagnostics(fmrx_pipeline *pl, unsigned *repaired_segments, float *max_dphase,
                                            float *max_dinteg);
-/* force the parameter-generic kernels (1) or allow the specialised ones (0) */
+/* force the parameter-generic kernels (1) or allow the specialised ones (0).  on = 1 is the BIT-EXACT
+ * mode: every stage keeps the reference's float32 evaluation order and fmPLL runs as the serial
+ * recurrence with glibc's functions, so mono AND stereo audio equal the reference's bit for bit for
+ * any stream length (the specialised kernels reorder sums, i.e. differ by ulps, which the stereo
+ * recurrence amplifies to its float32 phase grid: DESIGN.md section 2). */
 FMRX_API int fmrx_pipeline_set_force_generic(fmrx_pipeline *pl, int on);
+/* per-handle run-time option, names as for fmrx_set_option */
+FMRX_API int fmrx_pipeline_set_option(fmrx_pipeline *pl, const char *name, long value);
 
 /* ------------------------------------------------------------------ */
 /* fused front end (the hot kernel) as a stage of its own               */

@@ -16,6 +16,7 @@
 #pragma once
 #include <cstdint>
 #include <fstream>
+#include <iostream>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -182,6 +183,21 @@ inline void convertBlockData(const std::vector<uint8_t> &raw, std::vector<float>
     check(fmrx_u8_to_f32(raw.data(), raw.size(), block_data.data()));
 }
 
+// include/iofunc.h:36, src/iofunc.cpp:128-135 under its own name and signature: reads num_samples bytes
+// from std::cin and converts them on the device.  Like the reference it ignores block_id, leaves the
+// stream state for the caller to test (src/project.cpp:83), and on a short read converts the bytes it
+// got with the rest of the block as zero bytes (the reference's zero-initialised raw_data, Q6).
+// Define FMRX_FILTER_NO_IOFUNC to keep the reference's own iofunc.cpp in the link instead.
+#ifndef FMRX_FILTER_NO_IOFUNC
+inline void readStdinBlockData(unsigned int num_samples, unsigned int block_id, std::vector<float> &block_data)
+{
+    (void)block_id;
+    std::vector<uint8_t> raw(num_samples, 0);
+    std::cin.read(reinterpret_cast<char *>(raw.data()), num_samples * sizeof(char));
+    convertBlockData(raw, block_data);
+}
+#endif
+
 }  // namespace fmrx
 
 #ifndef FMRX_FILTER_NO_GLOBAL
@@ -196,6 +212,9 @@ using fmrx::estimatePSD;
 using fmrx::fmDemod;
 using fmrx::fmPLL;
 using fmrx::impulseResponseLPF;
+#ifndef FMRX_FILTER_NO_IOFUNC
+using fmrx::readStdinBlockData;
+#endif
 using fmrx::setVec;
 using fmrx::upsample;
 #endif

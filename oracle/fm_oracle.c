@@ -500,6 +500,11 @@ size_t fmo_pipeline_intermediate(const fmo_pipeline *pl, int which, const float 
     }
 }
 
+void fmo_libm(int fn, const float *a, const float *b, size_t n, float *out)
+{
+    for (size_t i = 0; i < n; i++) out[i] = fn == 0 ? sinf(a[i]) : fn == 1 ? cosf(a[i]) : atan2f(a[i], b[i]);
+}
+
 /* ------------------------------------------------------------------ */
 /* diagnostics: Bartlett PSD estimate                                     */
 /* ------------------------------------------------------------------ */

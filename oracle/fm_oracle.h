@@ -117,6 +117,11 @@ size_t fmo_pipeline_intermediate(const fmo_pipeline *pl, int which, const float 
  * Returns the number of segments averaged. */
 int fmo_estimate_psd(float *freq, float *psd, const float *samples, size_t n, float Fs, int nfft);
 
+/* out[i] = sinf(a[i]) (fn 0), cosf(a[i]) (fn 1), atan2f(a[i], b[i]) (fn 2) of this host's C library:
+ * what fmPLL's std::sin / std::cos / std::atan2 (src/filter.cpp:55,69-71) resolve to.  Lets a GPU test
+ * compare the device's restatement of these functions (csrc/glibc_libm.hpp) with the real ones. */
+void fmo_libm(int fn, const float *a, const float *b, size_t n, float *out);
+
 /* ---- deterministic synthetic FM multiplex ---------------- */
 /* Fills iq[2*n_samples] with constant-envelope stereo-multiplex FM at rf_Fs,
  * starting at absolute sample index start (so consecutive calls continue the

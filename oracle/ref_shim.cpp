@@ -209,6 +209,38 @@ ref_pipeline *ref_pipeline_create(int mode, int channels, int rf_taps, int base_
     return p;
 }
 
+// The same graph at parameter values outside the reference's mode table (BASELINE configs[2]: the course
+// spec's 2.5 MS/s -> 250 kS/s -> 48 / 40 kS/s, U/D = 24/125 / 4/25): project.cpp's setup with these numbers.
+// audio_taps is the total count (base taps x upsamp for a resampling mode).
+ref_pipeline *ref_pipeline_create_params(int rf_Fs, int if_fs, int rf_decim, int audio_decim, int audio_upsamp, int rf_taps,
+                                         int audio_taps, int stereo_taps, int channels)
+{
+    ref_pipeline *p = new ref_pipeline;
+    p->mode = audio_upsamp > 0 ? 2 : 0;   // selects the audio stage: resampler / decimating FIR
+    p->channels = channels;
+    p->rf_taps = rf_taps;
+    p->stereo_taps = stereo_taps;
+    p->rf_Fs = rf_Fs; p->if_fs = if_fs; p->rf_decim = rf_decim; p->audio_decim = audio_decim; p->audio_upsamp = audio_upsamp;
+    p->audio_taps = audio_taps;
+    int rf_Fc = 100000, audio_Fc = 16000;
+    impulseResponseLPF(p->rf_Fs, rf_Fc, rf_taps, p->rf_coeff);
+    if (audio_upsamp == 0) impulseResponseLPF(p->if_fs, audio_Fc, audio_taps, p->audio_coeff);
+    else impulseResponseLPF(p->if_fs * p->audio_upsamp, audio_Fc, audio_taps, p->audio_coeff);
+    p->I_state.resize(rf_taps - 1, 0.0);
+    p->Q_state.resize(rf_taps - 1, 0.0);
+    p->state_mono.resize(audio_taps - 1, 0.0f);
+    if (channels == 2) {
+        bandPass(p->if_fs, 18.5e3, 19.5e3, stereo_taps, p->carrier_coeff);
+        bandPass(p->if_fs, 22e3, 54e3, stereo_taps, p->stereo_coeff);
+        p->state_stereo.resize(stereo_taps - 1, 0.0f);
+        p->state_carrier.resize(stereo_taps - 1, 0.0f);
+        p->state_stereofilt.resize(audio_taps - 1, 0.0f);
+        p->state_allpass.resize(int((stereo_taps - 1) / 2), 0.0f);
+        p->state_PLL = std::vector<float>{0.0, 0.0, 1.0, 0.0, 1.0, 0};
+    }
+    return p;
+}
+
 void ref_pipeline_destroy(ref_pipeline *p) { delete p; }
 
 static void audio_stage(ref_pipeline *p, std::vector<float> &y, const std::vector<float> &x, std::vector<float> &st)

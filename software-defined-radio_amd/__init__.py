@@ -87,6 +87,8 @@ _sig("fmrx_version", [], C.c_char_p)
 _sig("fmrx_last_error", [], C.c_char_p)
 _sig("fmrx_device_count", [])
 _sig("fmrx_set_device", [_int])
+_sig("fmrx_set_option", [C.c_char_p, C.c_long])
+_sig("fmrx_get_option", [C.c_char_p, C.POINTER(C.c_long)])
 _sig("fmrx_host_alloc", [C.POINTER(_vp), _sz])
 _sig("fmrx_host_free", [_vp])
 _sig("fmrx_impulse_response_lpf", [_flt, _flt, C.c_ushort, _f32p])
@@ -106,6 +108,8 @@ _sig("fmrx_stereo_mix", [_f32p, _f32p, _sz, _f32p])
 _sig("fmrx_stereo_combine", [_f32p, _f32p, _sz, _f32p, _f32p])
 _sig("fmrx_pcm16", [_f32p, _sz, _i16p, _int])
 _sig("fmrx_estimate_psd", [_f32p, _f32p, _f32p, _sz, _flt, _int])
+_sig("fmrx_diag_libm", [_int, _f32p, _vp, _sz, _f32p])
+_sig("fmrx_diag_stream_read_dev", [_vp, _sz, _int, _vp])
 _sig("fmrx_mode_params", [_int, _int, _int, _int, C.POINTER(Params)])
 _sig("fmrx_pipeline_create", [C.POINTER(_vp), C.POINTER(Params), _int, _sz, _int])
 _sig("fmrx_pipeline_destroy", [_vp])
@@ -123,6 +127,7 @@ _sig("fmrx_pipeline_timing_sum", [_vp, _f32p, C.POINTER(_int), _int])
 _sig("fmrx_pipeline_set_profiling", [_vp, _int])
 _sig("fmrx_pipeline_set_force_generic", [_vp, _int])
 _sig("fmrx_pipeline_set_keep_intermediates", [_vp, _int])
+_sig("fmrx_pipeline_set_option", [_vp, C.c_char_p, C.c_long])
 _sig("fmrx_pipeline_pll_diagnostics", [_vp, C.POINTER(_uint), C.POINTER(_flt), C.POINTER(_flt)])
 _sig("fmrx_fe_fir_decim_u8", [_u8p, _sz, _f32p, _sz, _uint, _vp, _vp, _vp, _int])
 _sig("fmrx_fe_plan_create", [C.POINTER(_vp), _f32p, _sz, _uint])
@@ -155,6 +160,36 @@ def device_count() -> int:
 
 def set_device(dev: int) -> None:
     _check(lib.fmrx_set_device(dev))
+
+
+_FE_VARIANTS = {"mfma": 0, "valu": 1}
+
+
+def set_option(name: str, value) -> None:
+    """Process-wide default of a run-time option (include/fmrx.h: fmrx_set_option); pipelines created
+    afterwards start from it.  fe_variant also takes "mfma" / "valu"."""
+    _check(lib.fmrx_set_option(name.encode(), int(_FE_VARIANTS.get(value, value))))
+
+
+def get_option(name: str) -> int:
+    v = C.c_long(0)
+    _check(lib.fmrx_get_option(name.encode(), C.byref(v)))
+    return v.value
+
+
+def diagStreamRead(d_ptr, n_bytes, method=0, stream=None) -> None:
+    """One pure streaming read of a device buffer (fmrx_diag_stream_read_dev), async on `stream`."""
+    _check(lib.fmrx_diag_stream_read_dev(d_ptr, n_bytes, method, stream))
+
+
+def deviceLibm(fn: str, a, b=None) -> np.ndarray:
+    """sinf / cosf / atan2f as the device evaluates csrc/glibc_libm.hpp (fmrx_diag_libm): test hook."""
+    a = _f32(a)
+    out = np.zeros(len(a), np.float32)
+    bb = _f32(b) if b is not None else None
+    _check(lib.fmrx_diag_libm({"sinf": 0, "cosf": 1, "atan2f": 2}[fn], a, bb.ctypes.data if bb is not None else None,
+                              len(a), out))
+    return out
 
 
 # --------------------------------------------------------------------------
@@ -365,7 +400,12 @@ class Pipeline:
         return r.value, dp.value, di.value
 
     def set_force_generic(self, on=True):
+        """on: the bit-exact mode (reference evaluation order everywhere, serial PLL with glibc's functions)."""
         _check(lib.fmrx_pipeline_set_force_generic(self._h, int(on)))
+
+    def set_option(self, name: str, value):
+        """Per-handle run-time option (fmrx_pipeline_set_option); fe_variant also takes "mfma" / "valu"."""
+        _check(lib.fmrx_pipeline_set_option(self._h, name.encode(), int(_FE_VARIANTS.get(value, value))))
 
     def process(self, iq_u8, want_pcm=True, wrap=True):
         """One block of interleaved u8 I/Q (host) -> dict(audio=..., [audio_l, audio_r], pcm16=...)."""

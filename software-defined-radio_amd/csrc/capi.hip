@@ -41,6 +41,64 @@ int require_device()
     return FMRX_OK;
 }
 
+// ---- run-time options -----------------------------------------------------------
+bool option_ref(Options &o, const char *name, long **as_long, int **as_int)
+{
+    *as_long = nullptr;
+    *as_int = nullptr;
+    const std::string n = name ? name : "";
+    if (n == "fused_min_audio") *as_long = &o.fused_min_audio;
+    else if (n == "fe_variant") *as_int = &o.fe_variant;
+    else if (n == "resample_l2") *as_int = &o.resample_l2;
+    else if (n == "fe_wgs_per_cu") *as_int = &o.fe_wgs_per_cu;
+    else if (n == "pll_warmup") *as_int = &o.pll_warmup;
+    else if (n == "pll_segment") *as_int = &o.pll_segment;
+    else if (n == "pll_head") *as_int = &o.pll_head;
+    else if (n == "pll_mode") *as_int = &o.pll_mode;
+    else if (n == "fused_tune") *as_int = &o.fused_tune;
+    else if (n == "fe_mfma_tune") *as_int = &o.fe_mfma_tune;
+    else return false;
+    return true;
+}
+
+// built-in values, overridden once by the environment (first use; thread-safe static initialisation)
+Options &default_options()
+{
+    static Options o = [] {
+        Options d;
+        if (const char *e = std::getenv("FMRX_FE_VARIANT")) d.fe_variant = std::strcmp(e, "valu") == 0 ? 1 : 0;
+        if (const char *e = std::getenv("FMRX_FUSED_MIN_AUDIO")) d.fused_min_audio = std::atol(e);
+        if (std::getenv("FMRX_RESAMPLE_L2")) d.resample_l2 = 1;
+        if (const char *e = std::getenv("FMRX_FE_WGS_PER_CU")) d.fe_wgs_per_cu = std::atoi(e);
+        if (const char *e = std::getenv("FMRX_PLL_WARMUP")) d.pll_warmup = std::atoi(e);
+        if (const char *e = std::getenv("FMRX_PLL_SEGMENT")) d.pll_segment = std::atoi(e);
+        if (const char *e = std::getenv("FMRX_PLL_HEAD")) d.pll_head = std::atoi(e);
+        if (const char *e = std::getenv("FMRX_PLL_MODE")) d.pll_mode = std::atoi(e);
+#ifdef FMRX_TUNING
+        if (const char *e = std::getenv("FMRX_FUSED_TUNE")) d.fused_tune = std::atoi(e);
+        if (const char *e = std::getenv("FMRX_FE_MFMA_TUNE")) d.fe_mfma_tune = std::atoi(e);
+#endif
+        return d;
+    }();
+    return o;
+}
+
+int set_option_in(Options &o, const char *name, long value)
+{
+    long *pl = nullptr;
+    int *pi = nullptr;
+    if (!option_ref(o, name, &pl, &pi)) return fail(FMRX_EINVAL, "unknown option '%s'", name ? name : "(null)");
+#ifndef FMRX_TUNING
+    if ((pi == &o.fused_tune || pi == &o.fe_mfma_tune) && value != 0)
+        return fail(FMRX_EINVAL, "option '%s': ablation kernels exist only in a -DFMRX_TUNING build of libfmrx", name);
+#endif
+    if (pi == &o.fe_variant && value != 0 && value != 1) return fail(FMRX_EINVAL, "option fe_variant: 0 (mfma) or 1 (valu)");
+    if (pi == &o.pll_mode && (value < 0 || value > 2)) return fail(FMRX_EINVAL, "option pll_mode: 0, 1 or 2");
+    if (pl) *pl = value;
+    else *pi = static_cast<int>(value);
+    return FMRX_OK;
+}
+
 namespace {
 
 // per-thread device scratch for the host-buffer stage functions
@@ -80,7 +138,25 @@ using namespace fmrx;
 
 extern "C" {
 
-const char *fmrx_version(void) { return "fmrx 0.1 (gfx950)"; }
+const char *fmrx_version(void)
+{
+#ifdef FMRX_TUNING
+    return "fmrx 0.2 (gfx950, TUNING build: ablation kernels included)";
+#else
+    return "fmrx 0.2 (gfx950)";
+#endif
+}
+
+int fmrx_set_option(const char *name, long value) { return set_option_in(default_options(), name, value); }
+
+int fmrx_get_option(const char *name, long *value)
+{
+    long *pl = nullptr;
+    int *pi = nullptr;
+    if (!value || !option_ref(default_options(), name, &pl, &pi)) return fail(FMRX_EINVAL, "unknown option '%s'", name ? name : "(null)");
+    *value = pl ? *pl : *pi;
+    return FMRX_OK;
+}
 const char *fmrx_last_error(void) { return g_err; }
 
 int fmrx_device_count(void)
@@ -224,14 +300,17 @@ int fmrx_convolve_block_resample_fir(float *y, const float *x, size_t n, const f
     for (size_t d = 1; d <= H; d++) hist[H - d] = state[taps - 1 - d * upsamp];
     Scratch &s = scratch();
     const size_t n_out = (n * upsamp) / decim;
-    FMRX_TRY(s.a.ensure(H + n));
-    FMRX_TRY(s.h.ensure(taps));
+    const size_t Hp = (H + 3) / 4 * 4;   // keeps the block 16-byte aligned behind its history
+    FMRX_TRY(s.a.ensure(Hp + n));
     FMRX_TRY(s.b.ensure(n_out));
-    FMRX_TRY(h2d(s.a.p, hist.data(), H * sizeof(float)));
-    FMRX_TRY(h2d(s.a.p + H, x, n * sizeof(float)));
-    FMRX_TRY(h2d(s.h.p, h, taps * sizeof(float)));
-    FMRX_TRY(k_resample_generic(s.a.p + H, n, s.h.p, static_cast<int>(taps), static_cast<int>(decim),
-                                static_cast<int>(upsamp), s.b.p, nullptr));
+    FMRX_TRY(h2d(s.a.p + (Hp - H), hist.data(), H * sizeof(float)));
+    FMRX_TRY(h2d(s.a.p + Hp, x, n * sizeof(float)));
+    // polyphase-table kernels (bit-exact: the reference's operations in its order, kernels_resample.hip);
+    // the LDS-resident-table form from 65 536 outputs per call unless the option resample_l2 is set
+    ResamplePlan plan;
+    FMRX_TRY(resample_plan_init(plan, h, static_cast<int>(taps), static_cast<int>(decim), static_cast<int>(upsamp)));
+    FMRX_TRY(resample_launch(plan, s.a.p + Hp, n, 0, s.b.p, default_options(), nullptr, false));
+    FMRX_TRY(sync0());
     FMRX_TRY(d2h(y, s.b.p, n_out * sizeof(float)));
     // state refresh exactly as src/filter.cpp:218-222 (host copy): k = U-1; for
     // i = U*n-(taps-1); i < U*n-U; i += U: state[k] = x[i/U + 1]; k += U
@@ -359,6 +438,30 @@ int fmrx_stereo_combine(const float *stereo_final, const float *mono, size_t n, 
 }
 
 // ---- diagnostics ---------------------------------------------------------------------------
+int fmrx_diag_libm(int fn, const float *a, const float *b, size_t n, float *out)
+{
+    if (fn < 0 || fn > 2) return fail(FMRX_EINVAL, "diag_libm: fn must be 0 (sinf), 1 (cosf) or 2 (atan2f)");
+    if ((!a || !out || (fn == 2 && !b)) && n) return fail(FMRX_EINVAL, "diag_libm: null buffer");
+    FMRX_TRY(require_device());
+    Scratch &s = scratch();
+    FMRX_TRY(s.a.ensure(n));
+    FMRX_TRY(s.b.ensure(n));
+    FMRX_TRY(s.c.ensure(n));
+    FMRX_TRY(h2d(s.a.p, a, n * sizeof(float)));
+    if (fn == 2) FMRX_TRY(h2d(s.b.p, b, n * sizeof(float)));
+    FMRX_TRY(k_libm_eval(fn, s.a.p, s.b.p, n, s.c.p, nullptr));
+    return d2h(out, s.c.p, n * sizeof(float));
+}
+
+int fmrx_diag_stream_read_dev(const void *d_buf, size_t bytes, int method, void *stream)
+{
+    if (!d_buf || (method != 0 && method != 1)) return fail(FMRX_EINVAL, "diag_stream_read_dev: bad arguments");
+    FMRX_TRY(require_device());
+    static thread_local DevBuf<unsigned> sink;
+    FMRX_TRY(sink.ensure(4));
+    return k_stream_read(d_buf, bytes, method, sink.p, static_cast<hipStream_t>(stream));
+}
+
 int fmrx_estimate_psd(float *freq, float *psd, const float *samples, size_t n, float Fs, int nfft)
 {
     if (!freq || !psd || !samples) return fail(FMRX_EINVAL, "estimate_psd: null buffer");
@@ -412,7 +515,8 @@ int fmrx_fe_run_dev(const fmrx_fe_plan *plan, const uint8_t *d_iq, size_t n_samp
                     int force_generic, void *stream)
 {
     if (!plan || !d_iq || !d_if) return fail(FMRX_EINVAL, "fe_run_dev: null argument");
-    return fe_launch(plan->plan, d_iq, n_samples, d_hist, d_if, static_cast<hipStream_t>(stream), force_generic != 0);
+    return fe_launch(plan->plan, d_iq, n_samples, d_hist, d_if, default_options(), static_cast<hipStream_t>(stream),
+                     force_generic != 0);
 }
 
 int fmrx_fe_fir_decim_u8(const uint8_t *iq, size_t n_samples, const float *h, size_t taps, unsigned decim, uint8_t *hist,
@@ -439,7 +543,7 @@ int fmrx_fe_fir_decim_u8(const uint8_t *iq, size_t n_samples, const float *h, si
         FMRX_TRY(k_fill_u8(s.uh.p, hb, 128, nullptr));
         FMRX_TRY(h2d(s.uh.p + (hb - live), hist, live));
     }
-    FMRX_TRY(fe_launch(plan, s.u.p, n_samples, hist ? s.uh.p : nullptr, s.a.p, nullptr, force_generic != 0));
+    FMRX_TRY(fe_launch(plan, s.u.p, n_samples, hist ? s.uh.p : nullptr, s.a.p, default_options(), nullptr, force_generic != 0));
     FMRX_TRY(k_split_if(s.a.p, n_out, s.b.p, s.c.p, nullptr));
     if (if_i) FMRX_TRY(d2h(if_i, s.b.p, n_out * sizeof(float)));
     if (if_q) FMRX_TRY(d2h(if_q, s.c.p, n_out * sizeof(float)));

@@ -36,6 +36,29 @@ int fail(int code, const char *fmt, ...);
 // the caller returns FMRX_ENODEV.  There is deliberately no CPU path.
 int require_device();
 
+// ---- run-time options ----------------------------------------------------------
+// Process-wide defaults: the built-in values, overridden ONCE (first use) by the FMRX_* environment
+// variables named below, changed afterwards only through fmrx_set_option().  A pipeline handle copies
+// the defaults when it is created and keeps its own set (fmrx_pipeline_set_option); nothing on a
+// per-block launch path reads the environment.
+struct Options {
+    int fe_variant = 0;            // "fe_variant" / FMRX_FE_VARIANT: 0 = matrix-core kernels ("mfma"), 1 = vector-ALU kernels ("valu")
+    long fused_min_audio = 65536;  // "fused_min_audio" / FMRX_FUSED_MIN_AUDIO: audio samples per call from which the fused mono kernel runs
+    int resample_l2 = 0;           // "resample_l2" / FMRX_RESAMPLE_L2: 1 = L2-table resampler kernel even for large calls
+    int fe_wgs_per_cu = 0;         // "fe_wgs_per_cu" / FMRX_FE_WGS_PER_CU: cap on resident workgroups per CU of the front-end kernels (0 = auto)
+    int pll_warmup = -1;           // "pll_warmup" / FMRX_PLL_WARMUP: warm-up samples per lane of the parallel PLL (-1 = built-in)
+    int pll_segment = -1;          // "pll_segment" / FMRX_PLL_SEGMENT: samples per lane (-1 = built-in)
+    int pll_head = -1;             // "pll_head" / FMRX_PLL_HEAD: samples of a stream's first call walked serially (-1 = built-in)
+    int pll_mode = 0;              // "pll_mode" / FMRX_PLL_MODE: stereo PLL of the specialised pipeline: 0 = parallel in time, fast math
+                                   //   (default); 1 = serial, fast math; 2 = serial, glibc math (the cause-by-cause variants of DESIGN 2)
+    int fused_tune = 0;            // "fused_tune", "fe_mfma_tune": ablation variants, honoured only by a -DFMRX_TUNING build
+    int fe_mfma_tune = 0;
+};
+Options &default_options();
+// name -> field; returns false for an unknown name
+bool option_ref(Options &o, const char *name, long **as_long, int **as_int);
+int set_option_in(Options &o, const char *name, long value);   // validates; FMRX_EINVAL for unknown names / values
+
 // ---- small RAII device buffer ----------------------------------------------
 template <typename T>
 struct DevBuf {
@@ -80,9 +103,6 @@ struct FePlan {
     float scale_lo = 0.0f;
     DevBuf<uint8_t> silence;   // hist_bytes bytes of 128: the history of a stream that starts here
 };
-// FMRX_FE_VARIANT=valu selects the vector-ALU kernels (kernels_fe.hip) instead of the matrix-core ones;
-// read per call so one process can A/B them.
-bool fe_variant_mfma();
 constexpr int kFeMfmaDigits = 3;   // base-256 digits per tap: 24-bit fixed point
 int fe_plan_init(FePlan &pl, const float *h, int taps, int decim);
 // Matrix-core front end + discriminator: same contract as fe_demod_launch; d_demod may be NULL when
@@ -90,11 +110,11 @@ int fe_plan_init(FePlan &pl, const float *h, int taps, int decim);
 int fe_mfma_plan_init(FePlan &pl, const float *h, int taps, int decim);
 bool fe_mfma_available(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist);
 int fe_mfma_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist, const float *d_prev,
-                   float *d_demod, float *d_if, float *d_prev_out, uint8_t *d_hist_next, hipStream_t stream);
+                   float *d_demod, float *d_if, float *d_prev_out, uint8_t *d_hist_next, const Options &o, hipStream_t stream);
 // d_hist: hist_bytes bytes whose LAST 2*(taps-1) hold the previous samples.
 // Writes n_samples/decim float2 (I,Q) to d_if.
 int fe_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist, float *d_if,
-              hipStream_t stream, bool force_generic);
+              const Options &o, hipStream_t stream, bool force_generic);
 int fe_hist_bytes(int taps, int decim);
 // Fused front end + discriminator (the pipeline's kernel).  d_demod[n/decim] is
 // written; d_if (interleaved I,Q) and d_prev_out (float2 = IF[n/decim-1]) are
@@ -104,7 +124,7 @@ bool fe_fused_available(const FePlan &pl, const uint8_t *d_iq, size_t n_samples)
 // the block's last bytes there for the next block.
 int fe_demod_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist,
                     const float *d_prev_override, float *d_demod, float *d_if, float *d_prev_out,
-                    uint8_t *d_hist_next, hipStream_t stream);
+                    uint8_t *d_hist_next, const Options &o, hipStream_t stream);
 
 // ---- audio fast path (kernels_audio.hip) --------------------------------------
 struct AudioPlan {
@@ -122,7 +142,7 @@ int audio_mfma_table_init(AudioPlan &pl, const float *h, int taps, int decim);
 bool mono_fused_available(const FePlan &fe, const AudioPlan &au, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist);
 int mono_fused_launch(const FePlan &fe, const AudioPlan &au, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist,
                       const float *d_prev, const float *d_dhist_end, float *d_demod_tail, int tail_keep, float *d_prev_out,
-                      float *d_audio, int16_t *d_pcm, int wrap, uint8_t *d_hist_next, hipStream_t stream);
+                      float *d_audio, int16_t *d_pcm, int wrap, uint8_t *d_hist_next, const Options &o, hipStream_t stream);
 int audio_plan_init(AudioPlan &pl, const float *h, int taps, int decim);
 // y[k] = sum_n h[n] * x[decim*k - n - delay]; x points at the block start and
 // x[-(taps-1+delay+3) .. -1] must be readable history (the specialised kernel
@@ -147,8 +167,8 @@ struct ResamplePlan {
     DevBuf<float> h;           // plain taps (generic path)
 };
 int resample_plan_init(ResamplePlan &pl, const float *h, int taps, int decim, int upsamp);
-int resample_launch(const ResamplePlan &pl, const float *d_x, size_t n_in, int delay, float *d_y, hipStream_t stream,
-                    bool force_generic);
+int resample_launch(const ResamplePlan &pl, const float *d_x, size_t n_in, int delay, float *d_y, const Options &o,
+                    hipStream_t stream, bool force_generic);
 
 // ---- stereo band-pass pair (kernels_stereo.hip) ------------------------------------
 struct BpfPairPlan {
@@ -184,24 +204,31 @@ int k_pcm16(const float *d_a, size_t n, int16_t *d_out, int wrap, hipStream_t s)
 int k_pcm16_stereo(const float *d_l, const float *d_r, size_t n, int16_t *d_out, int wrap, hipStream_t s);
 int k_all_pass(const float *d_in, size_t n, const float *d_state, size_t nstate, float *d_out, hipStream_t s);
 // ---- pilot PLL (kernels_pll.hip) ----
-// serial form; fast != 0: shared double-precision argument reduction + hardware sin/cos
+// serial form.  fast == 0: the reference's recurrence with glibc's sinf/cosf/atan2f (glibc_libm.hpp) -- bit-identical
+// to the reference given bit-identical input; fast != 0: shared double-precision argument reduction + hardware sin/cos
 int k_fm_pll(const float *d_in, size_t n, float *d_out, float *d_state, float freq, float Fs, float ncoScale,
              float phaseAdjust, float normBandwidth, int fast, hipStream_t s);
-// parallel-in-time form (fast math): segments with warm-up, bit-for-bit verification against the
-// serial trajectory and serial repair where the loop was not locked.  d_scratch: pll_parallel_scratch_floats(n)
-// floats; d_scratch[2] (as u32) counts blocks that needed a repair (diagnostic).
+// parallel-in-time form (fast math): segments with warm-up, each checked against its predecessor's end state
+// within the merge tolerance below, serial repair where the loop was not locked.  Agrees with the serial
+// trajectory to within the float32 grid of trigArg, not bit for bit (kernels_pll.hip).  d_scratch:
+// pll_parallel_scratch_floats(n) floats; d_scratch[2] (as u32) counts segments that needed a repair (diagnostic).
 constexpr int kPllSegment = 512, kPllWarmup = 768;
 constexpr int kPllHead = 1024;   // samples of a stream's first call walked serially (acquisition) before the lanes take over
 // merge tolerance between a lane's warmed-up state and the true state (see kernels_pll.hip)
 constexpr float kPllTolPhase = 1e-2f, kPllTolInteg = 1e-4f;
 size_t pll_parallel_scratch_floats(size_t n);
 int k_fm_pll_parallel(const float *d_in, size_t n, float *d_out, float *d_state, float freq, float Fs, float ncoScale,
-                      float phaseAdjust, float normBandwidth, float *d_scratch, hipStream_t s);
+                      float phaseAdjust, float normBandwidth, float *d_scratch, const Options &o, hipStream_t s);
 int k_mix(const float *d_bpf, const float *d_pll, size_t n, float *d_mix, hipStream_t s);
 int k_combine(const float *d_st, const float *d_mono, size_t n, float *d_l, float *d_r, hipStream_t s);
 int k_upsample(const float *d_x, size_t n, float *d_xu, int up, hipStream_t s);
 int k_downsample(const float *d_in, size_t n_out, float *d_out, int ds, hipStream_t s);
 int k_fill_u8(uint8_t *d, size_t n, uint8_t v, hipStream_t s);
+// diagnostics: out[i] = sinf / cosf / atan2f (fn 0 / 1 / 2) of a[i] (, b[i]) as the device evaluates glibc_libm.hpp
+int k_libm_eval(int fn, const float *d_a, const float *d_b, size_t n, float *d_out, hipStream_t s);
+
+// ---- measurement aid (kernels_diag.hip): one pure streaming read of the buffer; method 0 registers (non-temporal), 1 LDS-DMA ring
+int k_stream_read(const void *d_buf, size_t bytes, int method, unsigned *d_sink, hipStream_t s);
 
 // ---- diagnostics (kernels_psd.hip) ---------------------------------------------------
 // d_seg_db: (n/nfft)*(nfft/2) floats of scratch; d_freq, d_psd: nfft/2 floats

@@ -18,8 +18,16 @@
 // drops up to 7 blocks nondeterministically) and the exit status is
 // 0 unless --compat-exit asks for the reference's 1.
 // Extra options (all --flags, never positional):
-//   --rf-taps N --audio-taps N --stereo-taps N   (defaults 101 101 101)
-//   --blocks-per-call K   process K reference-size blocks per device call
+//   --rf-taps N --audio-taps N --stereo-taps N   (defaults 101 101 101: the report's final choice,
+//                         doc/3DY4 Report.pdf p.7; neither shipped binary uses it)
+//   --like project        the tap counts of src/project.cpp as shipped:        13 / 13 / 13
+//   --like threadMonoOnly the tap counts of src/threadMonoOnly.cpp as shipped: 151 / 101
+//   --blocks-per-call K   process K reference-size blocks per device call (the stream is still cut into
+//                         reference-size blocks: at EOF every whole one is processed, only the trailing
+//                         partial reference block is dropped, exactly as with K = 1)
+//   --exact               the bit-exact mode (fmrx_pipeline_set_force_generic): every stage in the
+//                         reference's float32 evaluation order, serial PLL with glibc's functions --
+//                         stereo output equal to the reference's bit for bit for any stream length
 //   --saturate            clamp PCM instead of the reference's wrap-around
 //   --device N            HIP device ordinal
 //   --compat-exit         exit status 1 at EOF, like the reference
@@ -42,7 +50,8 @@ constexpr size_t kQueueElems = 6;
 // allocation, DMA-able by the GPU): `full` carries read blocks to the consumer,
 // `free_` returns them
 struct BlockQueue {
-    std::queue<int> full, free_;
+    std::queue<std::pair<int, size_t>> full;   // (pool index, bytes in it: whole reference blocks)
+    std::queue<int> free_;
     std::mutex m;
     std::condition_variable cv;
     bool done = false;
@@ -52,7 +61,7 @@ struct BlockQueue {
 {
     std::fprintf(stderr,
                  "Usage: %s [<mode 0-3> [<channels 1-2>]] [--rf-taps N] [--audio-taps N] [--stereo-taps N]\n"
-                 "          [--blocks-per-call K] [--saturate] [--device N] [--compat-exit]\n",
+                 "          [--like project|threadMonoOnly] [--blocks-per-call K] [--exact] [--saturate] [--device N] [--compat-exit]\n",
                  argv0);
     std::exit(1);
 }
@@ -61,7 +70,7 @@ struct BlockQueue {
 int main(int argc, char *argv[])
 {
     int mode = 0, channels = 1, rf_taps = 101, audio_taps = 101, stereo_taps = 101, device = 0, per_call = 1;
-    bool saturate = false, compat_exit = false;
+    bool saturate = false, compat_exit = false, exact = false;
     std::vector<std::string> pos;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -74,6 +83,14 @@ int main(int argc, char *argv[])
         else if (a == "--stereo-taps") next(stereo_taps);
         else if (a == "--blocks-per-call") next(per_call);
         else if (a == "--device") next(device);
+        else if (a == "--like") {
+            if (i + 1 >= argc) usage(argv[0]);
+            const std::string w = argv[++i];
+            if (w == "project") rf_taps = audio_taps = stereo_taps = 13;            // src/project.cpp:46, 424-429
+            else if (w == "threadMonoOnly") { rf_taps = 151; audio_taps = 101; }    // src/threadMonoOnly.cpp:66, 229-232
+            else usage(argv[0]);
+        }
+        else if (a == "--exact") exact = true;
         else if (a == "--saturate") saturate = true;
         else if (a == "--compat-exit") compat_exit = true;
         else if (a.rfind("--", 0) == 0) usage(argv[0]);
@@ -106,6 +123,10 @@ int main(int argc, char *argv[])
         std::fprintf(stderr, "fmrx: %s\n", fmrx_last_error());
         return 2;
     }
+    if (exact && fmrx_pipeline_set_force_generic(pl, 1) != FMRX_OK) {
+        std::fprintf(stderr, "fmrx: %s\n", fmrx_last_error());
+        return 2;
+    }
 
     constexpr int kPool = static_cast<int>(kQueueElems) + 2;   // 6 queued + 1 being read + 1 being processed
     std::vector<uint8_t *> pool(kPool, nullptr);
@@ -130,14 +151,14 @@ int main(int argc, char *argv[])
                 bq.free_.pop();
             }
             const size_t got = std::fread(pool[idx], 1, block_bytes, stdin);
+            // EOF inside a K-block chunk: its whole reference-size blocks still count; only the trailing
+            // partial reference block is ignored, as in the reference (src/project.cpp:78-83)
+            const size_t whole = got - got % static_cast<size_t>(p.block_bytes);
             std::lock_guard<std::mutex> lk(bq.m);
-            if (got != block_bytes) {  // EOF: the partial block is ignored, as in the reference
-                bq.done = true;
-                bq.cv.notify_all();
-                return;
-            }
-            bq.full.push(idx);
+            if (whole) bq.full.push({idx, whole});
+            if (got != block_bytes) bq.done = true;
             bq.cv.notify_all();
+            if (got != block_bytes) return;
         }
     });
 
@@ -155,18 +176,21 @@ int main(int argc, char *argv[])
     int rc = 0;
     for (;;) {
         int idx;
+        size_t bytes;
         {
             std::unique_lock<std::mutex> lk(bq.m);
             bq.cv.wait(lk, [&] { return !bq.full.empty() || bq.done; });
             if (bq.full.empty()) break;
-            idx = bq.full.front();
+            idx = bq.full.front().first;
+            bytes = bq.full.front().second;
             bq.full.pop();
         }
-        if (fmrx_pipeline_process(pl, pool[idx], block_bytes, nullptr, pcm,
+        const size_t n_pcm = fmrx_pipeline_n_audio(pl, bytes) * channels;
+        if (fmrx_pipeline_process(pl, pool[idx], bytes, nullptr, pcm,
                                   saturate ? FMRX_PCM_SATURATE : FMRX_PCM_WRAP) != FMRX_OK) {
             std::fprintf(stderr, "fmrx: %s\n", fmrx_last_error());
             rc = 3;
-        } else if (std::fwrite(pcm, sizeof(int16_t), n_out, stdout) != n_out) {
+        } else if (std::fwrite(pcm, sizeof(int16_t), n_pcm, stdout) != n_pcm) {
             std::fprintf(stderr, "fmrx: short write on stdout\n");
             rc = 4;
         }
@@ -176,7 +200,7 @@ int main(int argc, char *argv[])
             bq.cv.notify_all();
         }
         if (rc) break;
-        blocks++;
+        blocks += bytes / static_cast<size_t>(p.block_bytes);
     }
     if (rc != 0) {  // retire the producer
         std::lock_guard<std::mutex> lk(bq.m);
@@ -185,7 +209,7 @@ int main(int argc, char *argv[])
     }
     producer.join();
     std::fflush(stdout);
-    std::fprintf(stderr, "End of input stream reached after %zu blocks\n", blocks);
+    std::fprintf(stderr, "End of input stream reached after %zu reference-size blocks\n", blocks);
     fmrx_pipeline_destroy(pl);
     for (auto *b : pool) fmrx_host_free(b);
     fmrx_host_free(pcm);

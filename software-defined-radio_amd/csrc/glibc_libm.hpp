@@ -1,0 +1,301 @@
+// glibc_libm.hpp -- sinf / cosf / atan2f with the results of glibc 2.35 (x86-64, FMA-capable
+// host), restated for host and device so that the pilot PLL (kernels_pll.hip) can reproduce
+// the reference's recurrence bit for bit.
+//
+// Why this exists.  fmPLL (src/filter.cpp:52-72 of the reference) feeds std::cos / std::sin /
+// std::atan2 of float arguments back into a float32 recurrence.  The reference's arithmetic
+// therefore includes its C library: the third-party dependency is GNU libm, glibc 2.35
+// (Ubuntu 2.35-0ubuntu3.x in this image, here and on the GPU box), which is not part of
+// /root/reference.  Its algorithms for these three functions are published:
+//   * sinf / cosf: "sincosf" of ARM optimized-routines (Szabolcs Nagy, 2018), in glibc since
+//     2.28 as sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, s_sincosf.h; x86-64 builds select the
+//     variant compiled with -mfma on CPUs that have FMA (ifunc), whose double-precision
+//     polynomial steps are fused: the fma() calls below mark exactly those steps.
+//     Argument reduction: |x| < 120 multiply by 2/pi * 2^24 and round (reduce_fast);
+//     otherwise a 192-bit 4/pi table and integer arithmetic (reduce_large), exact.
+//   * atan2f / atanf: the float versions of Sun's fdlibm (e_atan2f.c, s_atanf.c), plain
+//     float32 operations in source order, no FMA (x86-64 baseline build).
+// This file restates those algorithms (nothing is copied from glibc's text; the constants
+// are the published ones).  It is PINNED by test, not by reading: tests/cpp/libm_check.cpp
+// compares every one of the 2^32 float arguments of sinf/cosf and >10^9 argument pairs of
+// atan2f against the C library of this image on the CPU (tests/test_libm_exact.py), and
+// tests/test_gpu_parity.py::test_device_libm_is_glibc runs the same comparison for the
+// device build on the GPU box.
+//
+// Host + device: every function is FMRX_HD.  Compile with FP contraction OFF (the pragma
+// below does it for clang/hipcc; g++ needs -ffp-contract=off).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define FMRX_HD __host__ __device__ __forceinline__
+#else
+#include <cmath>
+#define FMRX_HD inline
+#endif
+
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
+namespace fmrx {
+namespace glibc235 {
+
+FMRX_HD uint32_t f2u(float f)
+{
+#if defined(__HIPCC__)
+    return __builtin_bit_cast(uint32_t, f);
+#else
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+#endif
+}
+FMRX_HD float u2f(uint32_t u)
+{
+#if defined(__HIPCC__)
+    return __builtin_bit_cast(float, u);
+#else
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+#endif
+}
+FMRX_HD double fma64(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// ---- sinf / cosf -----------------------------------------------------------------------------
+// polynomial coefficients of sin and cos on [-pi/4, pi/4] (s_sincosf_data.c: __sincosf_table[0];
+// entry [1] holds the negated cosine coefficients, i.e. the negated result: rounding is symmetric)
+constexpr double kS1 = -0x1.555545995a603p-3, kS2 = 0x1.1107605230bc4p-7, kS3 = -0x1.994eb3774cf24p-13;
+constexpr double kC0 = 0x1p0, kC1 = -0x1.ffffffd0c621cp-2, kC2 = 0x1.55553e1068f19p-5, kC3 = -0x1.6c087e89a359dp-10,
+                 kC4 = 0x1.99343027bf8c3p-16;
+constexpr double kHpiInv = 0x1.45F306DC9C883p+23;   // 2/pi * 2^24
+constexpr double kHpi = 0x1.921FB54442D18p0;        // pi/2
+constexpr double kPi63 = 0x1.921FB54442D18p-62;     // pi / 2^63
+
+// sin(x) for the reduced argument; xs = x * (+-1), x2 = x*x
+FMRX_HD float sin_poly(double xs, double x2)
+{
+    const double x3 = xs * x2;
+    const double s1 = fma64(kS3, x2, kS2);
+    const double x7 = x3 * x2;
+    const double s = fma64(x3, kS1, xs);
+    return static_cast<float>(fma64(s1, x7, s));
+}
+// cos(x) for the reduced argument
+FMRX_HD float cos_poly(double x2)
+{
+    const double x4 = x2 * x2;
+    const double c2 = fma64(kC4, x2, kC3);
+    const double c1 = fma64(kC1, x2, kC0);
+    const double x6 = x4 * x2;
+    const double c = fma64(x4, kC2, c1);
+    return static_cast<float>(fma64(c2, x6, c));
+}
+
+// 4/pi in 32-bit windows, 8 bits apart (s_sincosf_data.c: __inv_pio4[24]): window i is bytes i .. i+3 of
+// 00 00 00 a2 f9 83 6e 4e 44 15 29 fc 27 57 d1 f5 34 dd c0 db 62 95 99 3c 43 90 41 (2/pi, 192 bits, behind
+// three zero bytes), big-endian.  Kept as 7 words so that a window is two words and a funnel shift.
+FMRX_HD uint32_t inv_pio4(int i)
+{
+    const uint32_t w[8] = {0x000000a2u, 0xf9836e4eu, 0x441529fcu, 0x2757d1f5u, 0x34ddc0dbu, 0x6295993cu, 0x43904100u, 0u};
+    const int q = i >> 2, s = (i & 3) * 8;
+    const uint64_t pair = (static_cast<uint64_t>(w[q]) << 32) | w[q + 1];
+    return static_cast<uint32_t>(pair >> (32 - s));
+}
+
+struct Reduced {
+    double x;    // reduced argument in [-pi/4, pi/4]
+    int n;       // quadrant (low two bits matter)
+};
+
+// |x| in [120, inf): multiply the 24-bit mantissa by 96 bits of 4/pi, exactly (integers)
+FMRX_HD Reduced reduce_large(uint32_t xi)
+{
+    const int idx = static_cast<int>((xi >> 26) & 15);
+    const int shift = static_cast<int>((xi >> 23) & 7);
+    uint32_t m = (xi & 0xffffffu) | 0x800000u;
+    m <<= shift;
+    uint64_t res0 = static_cast<uint32_t>(m * inv_pio4(idx));          // 32-bit product, as in the original
+    const uint64_t res1 = static_cast<uint64_t>(m) * inv_pio4(idx + 4);
+    const uint64_t res2 = static_cast<uint64_t>(m) * inv_pio4(idx + 8);
+    res0 = (res2 >> 32) | (res0 << 32);
+    res0 += res1;
+    const uint64_t n = (res0 + (1ull << 61)) >> 62;
+    res0 -= n << 62;
+    Reduced r;
+    r.x = static_cast<double>(static_cast<int64_t>(res0)) * kPi63;
+    r.n = static_cast<int>(n);
+    return r;
+}
+
+// |x| in [0.75, 120): n = round(x * 2/pi) through a scaled float->int conversion, x - n*pi/2 fused
+FMRX_HD Reduced reduce_fast(double x)
+{
+    const double r = x * kHpiInv;
+    const int n = (static_cast<int32_t>(r) + 0x800000) >> 24;
+    Reduced o;
+    o.n = n;
+    o.x = fma64(-static_cast<double>(n), kHpi, x);
+    return o;
+}
+
+FMRX_HD double quadrant_sign(int m) { return ((m + 1) & 2) ? -1.0 : 1.0; }   // {1, -1, -1, 1}[m & 3]
+
+// both values from one argument reduction; `want` bit 0: sine, bit 1: cosine
+FMRX_HD void sincosf_glibc(float y, float *sn, float *cs)
+{
+    const uint32_t xi = f2u(y);
+    const uint32_t top = (xi >> 20) & 0x7ff;
+    const double xd = static_cast<double>(y);
+    if (top < 0x3f4) {                 // |y| < 0.75 (the original compares the top 12 bits with those of pi/4)
+        const double x2 = xd * xd;
+        if (top < 0x398) {             // |y| < 2^-12
+            *sn = y;
+            *cs = 1.0f;
+            return;
+        }
+        *sn = sin_poly(xd, x2);
+        *cs = cos_poly(x2);
+        return;
+    }
+    Reduced r;
+    int m;
+    if (top < 0x42f) {                 // |y| < 120
+        r = reduce_fast(xd);
+        m = r.n;
+    } else if (top < 0x7f8) {
+        r = reduce_large(xi);
+        m = r.n + static_cast<int>(xi >> 31);
+    } else {                           // inf / NaN -> NaN
+        *sn = *cs = y - y;
+        return;
+    }
+    const double x2 = r.x * r.x;
+    const float sp = sin_poly(r.x * quadrant_sign(m), x2);
+    float cp = cos_poly(x2);
+    if (m & 2) cp = -cp;
+    // sine: quadrant n even -> sine polynomial, odd -> cosine polynomial; cosine: the other way round.
+    // The sign of the cosine branch depends on (m & 2) for the sine and on the same for the cosine:
+    //   sinf: sinf_poly(x*s, x2, table[(m>>1)&1], n)      cosf: sinf_poly(x*s, x2, table[(m>>1)&1], n ^ 1)
+    if (r.n & 1) {
+        *sn = cp;
+        *cs = sp;
+    } else {
+        *sn = sp;
+        *cs = cp;
+    }
+}
+
+FMRX_HD float sinf_glibc(float y)
+{
+    float s, c;
+    sincosf_glibc(y, &s, &c);
+    return s;
+}
+FMRX_HD float cosf_glibc(float y)
+{
+    float s, c;
+    sincosf_glibc(y, &s, &c);
+    return c;
+}
+
+// ---- atanf / atan2f (fdlibm, float) -------------------------------------------------------------
+FMRX_HD float atanf_glibc(float x)
+{
+    const float atanhi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
+    const float atanlo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
+    const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f, aT3 = -1.1111110449e-01f,
+                aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f, aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f,
+                aT8 = 4.9768779427e-02f, aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
+    const uint32_t hx = f2u(x);
+    const uint32_t ix = hx & 0x7fffffffu;
+    int id;
+    if (ix >= 0x4c000000u) {           // |x| >= 2^25
+        if (ix > 0x7f800000u) return x + x;
+        return (hx >> 31) ? -atanhi[3] - atanlo[3] : atanhi[3] + atanlo[3];
+    }
+    if (ix < 0x3ee00000u) {            // |x| < 0.4375
+        if (ix < 0x31000000u) return x;   // |x| < 2^-29
+        id = -1;
+    } else {
+        x = u2f(ix);                   // fabsf
+        if (ix < 0x3f980000u) {        // |x| < 1.1875
+            if (ix < 0x3f300000u) {    // 7/16 <= |x| < 11/16
+                id = 0;
+                x = (2.0f * x - 1.0f) / (2.0f + x);
+            } else {                   // 11/16 <= |x| < 19/16
+                id = 1;
+                x = (x - 1.0f) / (x + 1.0f);
+            }
+        } else {
+            if (ix < 0x401c0000u) {    // |x| < 2.4375
+                id = 2;
+                x = (x - 1.5f) / (1.0f + 1.5f * x);
+            } else {                   // 2.4375 <= |x| < 2^25
+                id = 3;
+                x = -1.0f / x;
+            }
+        }
+    }
+    const float z = x * x;
+    const float w = z * z;
+    const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    if (id < 0) return x - x * (s1 + s2);
+    const float r = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
+    return (hx >> 31) ? -r : r;
+}
+
+FMRX_HD float atan2f_glibc(float y, float x)
+{
+    const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f,
+                pi_lo = -8.7422776573e-08f;
+    const uint32_t hx = f2u(x), hy = f2u(y);
+    const uint32_t ix = hx & 0x7fffffffu, iy = hy & 0x7fffffffu;
+    if (ix > 0x7f800000u || iy > 0x7f800000u) return x + y;    // NaN
+    if (hx == 0x3f800000u) return atanf_glibc(y);              // x == 1
+    const int m = static_cast<int>((hy >> 31) & 1u) | static_cast<int>((hx >> 30) & 2u);   // 2*sign(x) + sign(y)
+    if (iy == 0) {                                             // y == +-0
+        switch (m) {
+        case 0:
+        case 1: return y;
+        case 2: return pi + tiny;
+        default: return -pi - tiny;
+        }
+    }
+    if (ix == 0) return (hy >> 31) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000u) {
+        if (iy == 0x7f800000u) {
+            switch (m) {
+            case 0: return pi_o_4 + tiny;
+            case 1: return -pi_o_4 - tiny;
+            case 2: return 3.0f * pi_o_4 + tiny;
+            default: return -3.0f * pi_o_4 - tiny;
+            }
+        }
+        switch (m) {
+        case 0: return 0.0f;
+        case 1: return -0.0f;
+        case 2: return pi + tiny;
+        default: return -pi - tiny;
+        }
+    }
+    if (iy == 0x7f800000u) return (hy >> 31) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    const int k = (static_cast<int>(iy) - static_cast<int>(ix)) >> 23;
+    float z;
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;                     // |y/x| > 2^60
+    else if ((hx >> 31) && k < -60) z = 0.0f;                  // |y|/x < -2^60
+    else z = atanf_glibc(u2f(f2u(y / x) & 0x7fffffffu));       // fabsf(y/x): one IEEE divide
+    switch (m) {
+    case 0: return z;
+    case 1: return u2f(f2u(z) ^ 0x80000000u);
+    case 2: return pi - (z - pi_lo);
+    default: return (z - pi_lo) - pi;
+    }
+}
+
+}  // namespace glibc235
+}  // namespace fmrx

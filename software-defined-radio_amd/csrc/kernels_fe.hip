@@ -7,16 +7,15 @@
 // the reference's run time -- and fmDemod
 // (src/project.cpp:128 -> src/filter.cpp:248-266).
 //
-// Three kernels share one arithmetic core (fe_compute):
+// Two kernels share one arithmetic core (fe_compute):
 //   fe_demod_kernel    the pipeline's kernel: FIR + discriminator, one WAVE per
 //                      tile, LDS-DMA staging, no workgroup barrier; writes demod
 //                      (4/D B per sample) and, on request, the IF stream
 //   fe_fir_kernel_pf   IF-only (behind fmrx_fe_run_dev): persistent workgroups,
 //                      next tile prefetched into registers
-//   fe_fir_kernel      IF-only, one tile per workgroup (baseline; FMRX_FE_VARIANT=1)
 //
 // This file is the vector-ALU generation of the front end (the north star's "no MFMA" form): kept,
-// tested, selected by FMRX_FE_VARIANT=valu.  The default kernels are the matrix-core ones of
+// tested, selected by the option fe_variant = valu (FMRX_FE_VARIANT=valu at start-up).  The default kernels are the matrix-core ones of
 // kernels_fe_mfma.hip (int8 MFMA on the raw bytes, exact integer arithmetic), which are HBM-bound
 // where this one is VALU-bound.
 //
@@ -200,47 +199,7 @@ __device__ __forceinline__ void fe_store(f2 *__restrict__ y, long kt, long n_out
     }
 }
 
-// Variant 1: one tile per workgroup; latency hiding by occupancy alone.
-template <int T, int D, int R, int NT>
-__global__ __launch_bounds__(NT) void fe_fir_kernel(const uint8_t *__restrict__ x, const uint8_t *__restrict__ hist,
-                                                     long n_bytes, const float *__restrict__ table,
-                                                     f2 *__restrict__ y, long n_out)
-{
-    using C = FeCfg<T, D, R, NT>;
-    extern __shared__ u4 lds[];
-    const int t = threadIdx.x;
-    const long k0 = static_cast<long>(blockIdx.x) * C::NOUT;  // first output of this tile
-    const long wbyte0 = 2L * D * k0 - C::HB;                  // byte offset of the tile window, multiple of 16
-
-    // ---- stage the tile's raw bytes: coalesced 16 B per lane ----
-    constexpr int NCHUNK = C::TILE_BYTES / 16;
-#pragma unroll
-    for (int c0i = 0; c0i < NCHUNK; c0i += NT) {
-        const int c = c0i + t;
-        if (c < NCHUNK) lds[c] = fe_fetch<C::HB>(x, hist, n_bytes, wbyte0 + 16L * c);
-    }
-    __syncthreads();
-
-    // ---- the thread's window: NB x 16 B, all register-resident ----
-    const u4 *lw = reinterpret_cast<const u4 *>(reinterpret_cast<const uint8_t *>(lds) + t * C::TSTRIDE);
-    uint32_t raw[C::NB * 4];
-#pragma unroll
-    for (int i = 0; i < C::NB; i++) {
-        const u4 v = lw[i];
-        raw[4 * i] = v.x;
-        raw[4 * i + 1] = v.y;
-        raw[4 * i + 2] = v.z;
-        raw[4 * i + 3] = v.w;
-    }
-
-    f2 acc[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) acc[r] = (f2){0.0f, 0.0f};
-    fe_compute<T, D, R, NT>(raw, table, acc);
-    fe_store<R>(y, k0 + static_cast<long>(t) * R, n_out, acc);
-}
-
-// Variant 2: persistent workgroups; the NEXT tile's bytes are fetched into
+// Persistent workgroups: the NEXT tile's bytes are fetched into
 // registers while this tile's FMAs run, so HBM latency sits under VALU work
 // instead of in front of a barrier.
 template <int T, int D, int R, int NT>
@@ -483,7 +442,7 @@ __global__ __launch_bounds__(256, (FeWaveCfg<T, D, R>::MINW)) void fe_demod_kern
 
 template <int T, int D, int R>
 int launch_fused(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist, const float *d_prev_override,
-                 float *d_demod, float *d_if, float *d_prev_out, uint8_t *d_hist_next, hipStream_t stream)
+                 float *d_demod, float *d_if, float *d_prev_out, uint8_t *d_hist_next, const Options &o, hipStream_t stream)
 {
     using W = FeWaveCfg<T, D, R>;
     if (d_hist) d_hist += pl.hist_bytes - W::HBX;   // the kernel reads the last HBX bytes of the history
@@ -493,10 +452,7 @@ int launch_fused(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const 
     long per_cu = (160 * 1024) / lds_wg;
     if (per_cu > 4) per_cu = 4;
     if (per_cu < 1) per_cu = 1;
-    if (const char *e = std::getenv("FMRX_FE_WGS_PER_CU")) {   // tuning knob (tools/fe_occ_ab.py)
-        const long v = std::atol(e);
-        if (v >= 1 && v < per_cu) per_cu = v;
-    }
+    if (o.fe_wgs_per_cu >= 1 && o.fe_wgs_per_cu < per_cu) per_cu = o.fe_wgs_per_cu;   // tuning knob
     const long want = (n_wtiles + 3) / 4;
     const unsigned grid = static_cast<unsigned>(want < 256 * per_cu ? want : 256 * per_cu);
     hipLaunchKernelGGL((fe_demod_kernel<T, D, R>), dim3(grid), dim3(256), static_cast<size_t>(lds_wg), stream, d_iq, d_hist,
@@ -508,14 +464,6 @@ int launch_fused(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const 
     return FMRX_OK;
 }
 
-// 1 = one tile per workgroup, 2 = persistent + register prefetch (default).
-// Read per launch so one process can A/B the two (tools/fe_ab.py).
-int fe_variant()
-{
-    const char *e = std::getenv("FMRX_FE_VARIANT");
-    return e ? std::atoi(e) : 2;
-}
-
 template <int T, int D>
 int launch_fast(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist, float *d_if,
                 hipStream_t stream)
@@ -524,11 +472,7 @@ int launch_fast(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const u
     using C = FeCfg<T, D, R, NT>;
     const long n_out = static_cast<long>(n_samples / D);
     const long n_tiles = (n_out + C::NOUT - 1) / C::NOUT;
-    if (fe_variant() == 1) {
-        hipLaunchKernelGGL((fe_fir_kernel<T, D, R, NT>), dim3(static_cast<unsigned>(n_tiles)), dim3(NT), C::TILE_BYTES,
-                           stream, d_iq, d_hist, static_cast<long>(2 * n_samples), pl.table.p,
-                           reinterpret_cast<f2 *>(d_if), n_out);
-    } else {
+    {
         // persistent: as many workgroups as fit at once (LDS allows 160 KiB / tile per CU)
         const long per_cu = (160 * 1024) / C::TILE_BYTES > 8 ? 8 : (160 * 1024) / C::TILE_BYTES;
         const long resident = 256 * (per_cu > 0 ? per_cu : 1);
@@ -537,7 +481,7 @@ int launch_fast(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const u
                            static_cast<long>(2 * n_samples), pl.table.p, reinterpret_cast<f2 *>(d_if), n_out, n_tiles);
     }
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(FMRX_EHIP, "launch fe_fir_kernel<%d,%d>: %s", T, D, hipGetErrorString(e));
+    if (e != hipSuccess) return fail(FMRX_EHIP, "launch fe_fir_kernel_pf<%d,%d>: %s", T, D, hipGetErrorString(e));
     return FMRX_OK;
 }
 
@@ -597,16 +541,16 @@ int fe_plan_init(FePlan &pl, const float *h, int taps, int decim)
 }
 
 int fe_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist, float *d_if,
-              hipStream_t stream, bool force_generic)
+              const Options &o, hipStream_t stream, bool force_generic)
 {
     if (n_samples / pl.decim == 0) return FMRX_OK;
     const bool aligned = (reinterpret_cast<uintptr_t>(d_iq) % 16 == 0) && ((2 * n_samples) % 16 == 0) &&
                          (!d_hist || reinterpret_cast<uintptr_t>(d_hist) % 16 == 0);
-    if (aligned && !force_generic && fe_variant_mfma() &&
+    if (aligned && !force_generic && o.fe_variant == 0 &&
         fe_mfma_available(pl, d_iq, n_samples, d_hist ? d_hist : pl.silence.p))
         // matrix-core kernel, IF stream only (S1: 2 + 8/D bytes per sample)
         return fe_mfma_launch(pl, d_iq, n_samples, d_hist ? d_hist : pl.silence.p, nullptr, nullptr, d_if, nullptr, nullptr,
-                              stream);
+                              o, stream);
     if (pl.fast && aligned && !force_generic) {
         // the IF-only kernels read just the last 2*(taps-1+lead) bytes of the history
         const uint8_t *h1 = d_hist ? d_hist + (pl.hist_bytes - fe_hist_base(pl.taps)) : nullptr;
@@ -625,13 +569,13 @@ bool fe_fused_available(const FePlan &pl, const uint8_t *d_iq, size_t n_samples)
 
 int fe_demod_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist,
                     const float *d_prev_override, float *d_demod, float *d_if, float *d_prev_out,
-                    uint8_t *d_hist_next, hipStream_t stream)
+                    uint8_t *d_hist_next, const Options &o, hipStream_t stream)
 {
     if (n_samples / pl.decim == 0) return FMRX_OK;
 #define X(T_, D_) \
     if (pl.taps == T_ && pl.decim == D_) \
         return launch_fused<T_, D_, 8>(pl, d_iq, n_samples, d_hist, d_prev_override, d_demod, d_if, d_prev_out, \
-                                       d_hist_next, stream);
+                                       d_hist_next, o, stream);
     FMRX_FE_CASES(X)
 #undef X
     return fail(FMRX_EINVAL, "fe_demod_launch: no specialised kernel for taps=%d decim=%d", pl.taps, pl.decim);

@@ -120,7 +120,7 @@ __device__ __forceinline__ void mf_dma_tile(const uint8_t *__restrict__ x, const
                                           ring + rs * C::SLOT, lane);
 }
 
-// DBG (tuning variants behind FMRX_FE_MFMA_TUNE, never dispatched by default):
+// DBG (ablation variants, compiled and dispatched only in a -DFMRX_TUNING build: option fe_mfma_tune):
 // 1 = no output stores, 2 = no MFMA work, 8 = non-temporal DMA
 template <int T, int D, int MINB, int PF, int DBG = 0>
 __global__ __launch_bounds__(256, MINB) void fe_mfma_kernel(
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256, MINB) void fe_mfma_kernel(
 
 template <int T, int D, int MINB = 2, int PF = 0, int DBG = 0>
 int launch_mfma(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist, const float *d_prev,
-                float *d_demod, float *d_if, float *d_prev_out, uint8_t *d_hist_next, hipStream_t stream)
+                float *d_demod, float *d_if, float *d_prev_out, uint8_t *d_hist_next, const Options &o, hipStream_t stream)
 {
     using C = MfCfg<T, D, PF>;
     if (C::LEAD > pl.hist_bytes) return fail(FMRX_EINVAL, "fe_mfma: history too short");
@@ -267,10 +267,7 @@ int launch_mfma(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const u
     const long n_tiles = (n_out + C::TILE_OUT - 1) / C::TILE_OUT;
     long wgs_per_cu = (160 * 1024) / (4L * C::RING);
     if (wgs_per_cu > MINB) wgs_per_cu = MINB;
-    if (const char *e = std::getenv("FMRX_FE_WGS_PER_CU")) {   // tuning knob
-        const long v = std::atol(e);
-        if (v >= 1 && v < wgs_per_cu) wgs_per_cu = v;
-    }
+    if (o.fe_wgs_per_cu >= 1 && o.fe_wgs_per_cu < wgs_per_cu) wgs_per_cu = o.fe_wgs_per_cu;   // tuning knob
     const long want = (n_tiles + 3) / 4;
     const long grid = want < 256 * wgs_per_cu ? want : 256 * wgs_per_cu;
     hipLaunchKernelGGL((fe_mfma_kernel<T, D, MINB, PF, DBG>), dim3(static_cast<unsigned>(grid)), dim3(256), 4 * C::RING, stream, d_iq,
@@ -348,8 +345,8 @@ __device__ __forceinline__ void fu_dma_slot(const uint8_t *__restrict__ x, const
                                      ring + rs * C::TILE_BYTES, lane);
 }
 
-// PF / DRF / KPTF override P / DR / KPT, DBG compiles parts out -- ablation variants behind FMRX_FUSED_TUNE
-// (tools/fused_tune.py; DESIGN.md section 5 quotes them), never dispatched by default.  DBG bits: 1 = no audio
+// PF / DRF / KPTF override P / DR / KPT, DBG compiles parts out -- ablation variants (tools/fused_tune.py;
+// DESIGN.md section 5 quotes them), compiled and dispatched only in a -DFMRX_TUNING build (option fused_tune).  DBG bits: 1 = no audio
 // work at all, 2 = the audio MFMAs replaced by one v_fma each, 4 = no byte flip (wrong results, timing
 // only), 8 = audio stores compiled out.
 template <int T, int D, int TA, int DA, int PF = 0, int DRF = 0, int DBG = 0, int KPTF = 0>
@@ -597,9 +594,10 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
 template <int T, int D, int TA, int DA, int PF = 0, int DRF = 0, int DBG = 0, int KPTF = 0>
 int launch_fused_mono(const FePlan &fe, const AudioPlan &au, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist,
                       const float *d_prev, const float *d_dhist_end, float *d_demod_tail, int tail_keep, float *d_prev_out,
-                      float *d_audio, int16_t *d_pcm, int wrap, uint8_t *d_hist_next, hipStream_t stream)
+                      float *d_audio, int16_t *d_pcm, int wrap, uint8_t *d_hist_next, const Options &o, hipStream_t stream)
 {
     using C = FuCfg<T, D, TA, DA, PF, DRF, KPTF>;
+    (void)o;
     if (C::F::FRONT > fe.hist_bytes) return fail(FMRX_EINVAL, "mono_fused: history too short");
     const long n_out = static_cast<long>(n_samples / D);
     const long n_tiles = (n_out + C::TILE_OUT - 1) / C::TILE_OUT;
@@ -665,12 +663,6 @@ int fe_mfma_plan_init(FePlan &pl, const float *h, int taps, int decim)
     return FMRX_OK;
 }
 
-bool fe_variant_mfma()
-{
-    const char *e = std::getenv("FMRX_FE_VARIANT");
-    return !(e && std::strcmp(e, "valu") == 0);
-}
-
 bool fe_mfma_available(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist)
 {
     return pl.mfma && d_hist && n_samples >= 8 && (reinterpret_cast<uintptr_t>(d_iq) % 16 == 0) &&
@@ -678,26 +670,27 @@ bool fe_mfma_available(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, 
 }
 
 int fe_mfma_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist, const float *d_prev,
-                   float *d_demod, float *d_if, float *d_prev_out, uint8_t *d_hist_next, hipStream_t stream)
+                   float *d_demod, float *d_if, float *d_prev_out, uint8_t *d_hist_next, const Options &o, hipStream_t stream)
 {
     if (n_samples / pl.decim == 0) return FMRX_OK;
     if (!d_demod && !d_if) return fail(FMRX_EINVAL, "fe_mfma_launch: no output");
-    if (const char *e = std::getenv("FMRX_FE_MFMA_TUNE")) {   // "<workgroups per CU><tiles in flight>", (101,10) only
-        const int v = std::atoi(e);
+#ifdef FMRX_TUNING
+    if (const int v = o.fe_mfma_tune) {   // "<workgroups per CU><tiles in flight>", (101,10) only
 #define Y(B_, P_) \
     if (pl.taps == 101 && pl.decim == 10 && v == B_ * 10 + P_) \
-        return launch_mfma<101, 10, B_, P_>(pl, d_iq, n_samples, d_hist, d_prev, d_demod, d_if, d_prev_out, d_hist_next, stream);
+        return launch_mfma<101, 10, B_, P_>(pl, d_iq, n_samples, d_hist, d_prev, d_demod, d_if, d_prev_out, d_hist_next, o, stream);
         Y(2, 2) Y(2, 3) Y(2, 4) Y(3, 3) Y(4, 3) Y(1, 3)
 #undef Y
 #define Y(G_) \
     if (pl.taps == 101 && pl.decim == 10 && v == G_ * 100 + 23) \
-        return launch_mfma<101, 10, 2, 3, G_>(pl, d_iq, n_samples, d_hist, d_prev, d_demod, d_if, d_prev_out, d_hist_next, stream);
+        return launch_mfma<101, 10, 2, 3, G_>(pl, d_iq, n_samples, d_hist, d_prev, d_demod, d_if, d_prev_out, d_hist_next, o, stream);
         Y(1) Y(2) Y(3) Y(8)
 #undef Y
     }
+#endif
 #define X(T_, D_) \
     if (pl.taps == T_ && pl.decim == D_) \
-        return launch_mfma<T_, D_>(pl, d_iq, n_samples, d_hist, d_prev, d_demod, d_if, d_prev_out, d_hist_next, stream);
+        return launch_mfma<T_, D_>(pl, d_iq, n_samples, d_hist, d_prev, d_demod, d_if, d_prev_out, d_hist_next, o, stream);
     FMRX_FE_MFMA_CASES(X)
 #undef X
     return fail(FMRX_EINVAL, "fe_mfma_launch: no kernel for taps=%d decim=%d", pl.taps, pl.decim);
@@ -730,23 +723,24 @@ bool mono_fused_available(const FePlan &fe, const AudioPlan &au, const uint8_t *
 
 int mono_fused_launch(const FePlan &fe, const AudioPlan &au, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist,
                       const float *d_prev, const float *d_dhist_end, float *d_demod_tail, int tail_keep, float *d_prev_out,
-                      float *d_audio, int16_t *d_pcm, int wrap, uint8_t *d_hist_next, hipStream_t stream)
+                      float *d_audio, int16_t *d_pcm, int wrap, uint8_t *d_hist_next, const Options &o, hipStream_t stream)
 {
     if (!d_prev || !d_dhist_end || !d_demod_tail) return fail(FMRX_EINVAL, "mono_fused_launch: null argument");
-    if (const char *e = std::getenv("FMRX_FUSED_TUNE")) {   // tuning variants, (101,10,101,5) only
-        const int v = std::atoi(e);
+#ifdef FMRX_TUNING
+    if (const int v = o.fused_tune) {   // ablation variants, (101,10,101,5) only
 #define Y(ID_, P_, DR_, G_, K_)                                                                                            \
     if (fe.taps == 101 && fe.decim == 10 && au.taps == 101 && au.decim == 5 && v == ID_)                                    \
         return launch_fused_mono<101, 10, 101, 5, P_, DR_, G_, K_>(fe, au, d_iq, n_samples, d_hist, d_prev, d_dhist_end,    \
                                                                   d_demod_tail, tail_keep, d_prev_out, d_audio, d_pcm, wrap, \
-                                                                  d_hist_next, stream);
+                                                                  d_hist_next, o, stream);
         Y(2, 2, 0, 0, 0) Y(12, 2, 0, 1, 0) Y(1, 1, 0, 0, 0) Y(82, 2, 0, 8, 0) Y(102, 2, 0, 10, 0)
 #undef Y
     }
+#endif
 #define X(T_, D_, TA_, DA_)                                                                                          \
     if (fe.taps == T_ && fe.decim == D_ && au.taps == TA_ && au.decim == DA_)                                         \
         return launch_fused_mono<T_, D_, TA_, DA_>(fe, au, d_iq, n_samples, d_hist, d_prev, d_dhist_end, d_demod_tail, \
-                                                   tail_keep, d_prev_out, d_audio, d_pcm, wrap, d_hist_next, stream);
+                                                   tail_keep, d_prev_out, d_audio, d_pcm, wrap, d_hist_next, o, stream);
     FMRX_FUSED_CASES(X)
 #undef X
     return fail(FMRX_EINVAL, "mono_fused_launch: no kernel for this filter shape");

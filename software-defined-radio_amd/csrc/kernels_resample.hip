@@ -183,14 +183,14 @@ int resample_plan_init(ResamplePlan &pl, const float *h, int taps, int decim, in
 }
 
 // x points at the block start; x[-(J-1+delay) .. -1] must be readable history
-int resample_launch(const ResamplePlan &pl, const float *d_x, size_t n_in, int delay, float *d_y, hipStream_t stream,
-                    bool force_generic)
+int resample_launch(const ResamplePlan &pl, const float *d_x, size_t n_in, int delay, float *d_y, const Options &o,
+                    hipStream_t stream, bool force_generic)
 {
     const size_t n_out = (n_in * static_cast<size_t>(pl.upsamp)) / pl.decim;
     if (n_out == 0) return FMRX_OK;
     if (!pl.fast || force_generic)
         return k_resample_generic(d_x - delay, n_in, pl.h.p, pl.taps, pl.decim, pl.upsamp, d_y, stream);
-    if (pl.npass > 0 && n_out >= 64 * kLT && std::getenv("FMRX_RESAMPLE_L2") == nullptr) {
+    if (pl.npass > 0 && n_out >= 64 * kLT && !o.resample_l2) {
         const size_t lds_bytes = (static_cast<size_t>(pl.upsamp) * (pl.W + kRowPad) + pl.span_l) * sizeof(float);
         if (lds_bytes > 64 * 1024) {   // more dynamic LDS than the default cap: opt in, once per device
             static bool raised[64] = {};

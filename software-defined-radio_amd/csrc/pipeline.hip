@@ -43,6 +43,7 @@ struct fmrx_pipeline {
     bool if_valid = false;       // ifb holds the last block's IF samples
     bool demod_valid = true;     // the demod buffer holds the whole last block (not just its tail: fused mono kernel)
     bool pll_warm = false;       // the PLL has seen a block since reset / set_state (its state is a locked one)
+    Options opt;                 // copied from the process defaults at creation; fmrx_pipeline_set_option
 
     hipStream_t stream = nullptr;  // used by the host-buffer entry point
     FePlan fe;
@@ -88,14 +89,9 @@ __global__ void hist_update_kernel(const uint8_t *__restrict__ old_hist, const u
     new_hist[i] = src >= 0 ? x[src] : old_hist[hb + src];
 }
 
-// The fused mono kernel gives each wave whole batches of 256 audio samples; below this many audio
-// samples per call there are too few batches to fill the chip and the two-kernel path is used.
-// FMRX_FUSED_MIN_AUDIO overrides (0 = always fuse when possible, a huge value = never).
-size_t fused_min_audio()
-{
-    if (const char *e = std::getenv("FMRX_FUSED_MIN_AUDIO")) return static_cast<size_t>(std::atoll(e));
-    return 256 * 256;
-}
+// The fused mono kernel gives each wave whole batches of 256 audio samples; below opt.fused_min_audio
+// (default 65 536) audio samples per call there are too few batches to fill the chip and the two-kernel
+// path is used (0 = always fuse when possible, a huge value = never).
 
 int n_if_of(const fmrx_pipeline *pl, size_t n_bytes) { return static_cast<int>((n_bytes / 2) / pl->p.rf_decim); }
 
@@ -118,7 +114,7 @@ int carry_history(fmrx_pipeline *pl, float *buf, int keep, size_t n_block, hipSt
 
 int audio_stage(fmrx_pipeline *pl, const float *d_x, size_t n_in, int delay, float *d_y, hipStream_t s)
 {
-    if (pl->resample) return resample_launch(pl->rs, d_x, n_in, delay, d_y, s, pl->force_generic);
+    if (pl->resample) return resample_launch(pl->rs, d_x, n_in, delay, d_y, pl->opt, s, pl->force_generic);
     return audio_fir_launch(pl->audio, d_x, nullptr, n_in, delay, d_y, nullptr, 0, s, pl->force_generic);
 }
 
@@ -190,6 +186,7 @@ int fmrx_pipeline_create(fmrx_pipeline **out, const fmrx_params *p, int channels
     FMRX_HIP(hipSetDevice(device));
 
     fmrx_pipeline *pl = new fmrx_pipeline;
+    pl->opt = default_options();
     pl->p = *p;
     pl->channels = channels;
     pl->device = device;
@@ -310,6 +307,12 @@ int fmrx_pipeline_pll_diagnostics(fmrx_pipeline *pl, unsigned *repaired_segments
     return FMRX_OK;
 }
 
+int fmrx_pipeline_set_option(fmrx_pipeline *pl, const char *name, long value)
+{
+    if (!pl) return fail(FMRX_EINVAL, "null handle");
+    return set_option_in(pl->opt, name, value);
+}
+
 int fmrx_pipeline_set_keep_intermediates(fmrx_pipeline *pl, int on)
 {
     if (!pl) return fail(FMRX_EINVAL, "null handle");
@@ -362,15 +365,18 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
     float *prev_next = pl->prev_iq[pl->prev_cur ^ 1].p;
     bool hist_done = false;
     pl->demod_valid = true;
-    if (pl->channels == 1 && !pl->resample && !pl->force_generic && !pl->keep_if && fe_variant_mfma() &&
-        n_if >= static_cast<size_t>(pl->Hd) && n_au >= fused_min_audio() &&
+    const bool mfma = pl->opt.fe_variant == 0;
+    if (pl->channels == 1 && !pl->resample && !pl->force_generic && !pl->keep_if && mfma &&
+        n_if >= static_cast<size_t>(pl->Hd) && static_cast<long>(n_au) >= pl->opt.fused_min_audio &&
         mono_fused_available(pl->fe, pl->audio, d_iq, n, hist)) {
         // ---- RF_FrontEnd + RF_MONO of modes 0/1 in one kernel (kernels_fe_mfma.hip): the discriminator
         //      output stays on chip; only its tail (state_mono) is written for the next block ----
         hist_done = n_bytes >= static_cast<size_t>(hb);
-        float *dst = d_audio_f32 ? d_audio_f32 : pl->mono.p;
+        // f32 audio is written only where somebody will read it: the caller's buffer, or the handle's own when
+        // no PCM was asked for either (read_tap); PCM-only callers get the reference's output format and nothing else
+        float *dst = d_audio_f32 ? d_audio_f32 : (d_pcm16 ? nullptr : pl->mono.p);
         FMRX_TRY(mono_fused_launch(pl->fe, pl->audio, d_iq, n, hist, prev, hist_end, demod, pl->Hd, prev_next, dst, d_pcm16,
-                                   pcm_policy, hist_done ? hist_next : nullptr, s));
+                                   pcm_policy, hist_done ? hist_next : nullptr, pl->opt, s));
         pl->if_valid = false;
         pl->demod_valid = false;
         pl->last_mono = dst;
@@ -390,22 +396,22 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
         }
         return FMRX_OK;
     }
-    if (!pl->force_generic && fe_variant_mfma() && fe_mfma_available(pl->fe, d_iq, n, hist)) {
+    if (!pl->force_generic && mfma && fe_mfma_available(pl->fe, d_iq, n, hist)) {
         // matrix-core kernel: int8 MFMA FIR + discriminator, HBM-bound (kernels_fe_mfma.hip)
         hist_done = n_bytes >= static_cast<size_t>(hb);
         FMRX_TRY(fe_mfma_launch(pl->fe, d_iq, n, hist, pl->prev_override ? prev : nullptr, demod,
                                 pl->keep_if ? pl->ifb.p : nullptr, prev_next,
-                                hist_done ? hist_next : nullptr, s));
+                                hist_done ? hist_next : nullptr, pl->opt, s));
         pl->if_valid = pl->keep_if;
     } else if (!pl->force_generic && fe_fused_available(pl->fe, d_iq, n)) {
         // one kernel; the IF stream is written only when somebody asked to look at it, and the kernel
         // also leaves the stream's last bytes (I_state/Q_state, filter.cpp:182-187) for the next block
         hist_done = n_bytes >= static_cast<size_t>(hb);
         FMRX_TRY(fe_demod_launch(pl->fe, d_iq, n, hist, pl->prev_override ? prev : nullptr, demod,
-                                 pl->keep_if ? pl->ifb.p : nullptr, prev_next, hist_done ? hist_next : nullptr, s));
+                                 pl->keep_if ? pl->ifb.p : nullptr, prev_next, hist_done ? hist_next : nullptr, pl->opt, s));
         pl->if_valid = pl->keep_if;
     } else {
-        FMRX_TRY(fe_launch(pl->fe, d_iq, n, hist, pl->ifb.p, s, pl->force_generic));
+        FMRX_TRY(fe_launch(pl->fe, d_iq, n, hist, pl->ifb.p, pl->opt, s, pl->force_generic));
         FMRX_TRY(k_fm_demod_if(pl->ifb.p, n_if, prev, prev_next, demod, 0, s));
         pl->if_valid = true;
     }
@@ -452,23 +458,24 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
         FMRX_TRY(audio_stage(pl, demod, n_if, pl->delay, pl->mono.p, s));  // all-pass = index offset
         if (prof) FMRX_HIP(hipEventRecord(ev[2], s));
         FMRX_TRY(bpf_pair_launch(pl->bpf_plan, demod, n_if, pl->bpf.p, pl->carrier.p, s, pl->force_generic));
-        if (pl->force_generic)
+        if (pl->force_generic || pl->opt.pll_mode != 0) {
+            // the serial recurrence: glibc's functions in the bit-exact mode (and pll_mode 2), fast math for pll_mode 1
+            const int fast = !pl->force_generic && pl->opt.pll_mode == 1;
             FMRX_TRY(k_fm_pll(pl->carrier.p, n_if, pl->pll.p, pl->pll_state.p, 19e3f, static_cast<float>(p.if_Fs), 2.0f,
-                              0.0f, 0.01f, 0, s));
-        else {
+                              0.0f, 0.01f, fast, s));
+        } else {
             // a stream's first block starts unlocked: walk its first samples serially so that the
             // segment lanes extrapolate from a locked state; later blocks start locked already
             size_t head = 0;
             if (!pl->pll_warm) {
-                size_t head_len = kPllHead;
-                if (const char *e = std::getenv("FMRX_PLL_HEAD")) head_len = static_cast<size_t>(std::atol(e));   // tuning
+                const size_t head_len = pl->opt.pll_head >= 0 ? static_cast<size_t>(pl->opt.pll_head) : kPllHead;
                 head = n_if < head_len ? n_if : head_len;
                 FMRX_TRY(k_fm_pll(pl->carrier.p, head, pl->pll.p, pl->pll_state.p, 19e3f, static_cast<float>(p.if_Fs),
                                   2.0f, 0.0f, 0.01f, 1, s));
             }
             if (n_if > head)
                 FMRX_TRY(k_fm_pll_parallel(pl->carrier.p + head, n_if - head, pl->pll.p + head, pl->pll_state.p, 19e3f,
-                                           static_cast<float>(p.if_Fs), 2.0f, 0.0f, 0.01f, pl->pll_scratch.p, s));
+                                           static_cast<float>(p.if_Fs), 2.0f, 0.0f, 0.01f, pl->pll_scratch.p, pl->opt, s));
             pl->pll_warm = true;
         }
         FMRX_TRY(k_mix(pl->bpf.p, pl->pll.p, n_if, mixer, s));
@@ -531,7 +538,10 @@ int fmrx_pipeline_read_tap(fmrx_pipeline *pl, int which, float *out, size_t *n)
         // tail copy kept in front when the block is shorter than that -- simplest: the
         // block region itself is still intact (carry copies, it does not move)
         src = pl->demod_buf[pl->demod_last].p + pl->Hd; cnt = n_if; break;
-    case FMRX_TAP_MONO: src = pl->last_mono ? pl->last_mono : pl->mono.p; cnt = n_au; break;
+    case FMRX_TAP_MONO:
+        src = pl->last_mono; cnt = n_au;
+        if (!src && out && cnt) return fail(FMRX_EINVAL, "read_tap: the last call wrote s16 PCM only (no f32 audio buffer was passed)");
+        break;
     case FMRX_TAP_CARRIER: if (st) { src = pl->carrier.p; cnt = n_if; } break;
     case FMRX_TAP_STEREO_BPF: if (st) { src = pl->bpf.p; cnt = n_if; } break;
     case FMRX_TAP_PLL: if (st) { src = pl->pll.p; cnt = n_if + 1; } break;

@@ -162,6 +162,7 @@ class Oracle(_FirFamily):
         self._sig("fmo_pipeline_intermediate", C.c_size_t, [C.c_void_p, C.c_int, C.POINTER(C.POINTER(C.c_float))])
         self._sig("fmo_synth_fm_u8", None, [u8p, C.c_size_t, C.c_double, C.c_uint64, C.c_uint64])
         self._sig("fmo_estimate_psd", C.c_int, [f32p, f32p, f32p, C.c_size_t, C.c_float, C.c_int])
+        self._sig("fmo_libm", None, [C.c_int, f32p, f32p, C.c_size_t, f32p])
 
     def u8_to_f32(self, raw):
         raw = np.ascontiguousarray(raw, np.uint8)
@@ -194,6 +195,17 @@ class Oracle(_FirFamily):
 
     def pipeline(self, mode=0, channels=1, rf_taps=101, base_audio_taps=101, stereo_taps=101):
         return OraclePipeline(self, self.mode_params(mode, rf_taps, base_audio_taps, stereo_taps), channels)
+
+    def pipeline_params(self, params: FmoParams, channels=1):
+        return OraclePipeline(self, params, channels)
+
+    def libm(self, fn: str, a, b=None) -> np.ndarray:
+        """sinf / cosf / atan2f of this host's C library (what the reference calls)."""
+        a = _f32(a)
+        b = _f32(b) if b is not None else a
+        out = np.zeros(len(a), np.float32)
+        self.lib.fmo_libm({"sinf": 0, "cosf": 1, "atan2f": 2}[fn], a, b, len(a), out)
+        return out
 
 
 class OraclePipeline:
@@ -239,6 +251,8 @@ class Ref(_FirFamily):
         self._sig("ref_pipeline_create", C.c_void_p, [C.c_int] * 5)
         if hasattr(self.lib, "ref_estimate_psd"):
             self._sig("ref_estimate_psd", C.c_int, [f32p, f32p, f32p, C.c_size_t, C.c_float])
+        if hasattr(self.lib, "ref_pipeline_create_params"):
+            self._sig("ref_pipeline_create_params", C.c_void_p, [C.c_int] * 9)
         self._sig("ref_pipeline_destroy", None, [C.c_void_p])
         self._sig("ref_pipeline_process", C.c_size_t, [C.c_void_p, u8p, C.c_size_t])
         self._sig("ref_pipeline_get", C.c_size_t, [C.c_void_p, C.c_int, C.POINTER(C.POINTER(C.c_float))])
@@ -267,6 +281,14 @@ class Ref(_FirFamily):
 
     def pipeline(self, mode=0, channels=1, rf_taps=101, base_audio_taps=101, stereo_taps=101):
         return RefPipeline(self, mode, channels, rf_taps, base_audio_taps, stereo_taps)
+
+    def pipeline_params(self, p, channels=1):
+        """The reference's graph at explicit parameters (FmoParams-like: rf_Fs, if_Fs, rf_decim, ...)."""
+        rp = RefPipeline.__new__(RefPipeline)
+        rp.r, rp.channels = self, channels
+        rp.h = self.lib.ref_pipeline_create_params(p.rf_Fs, p.if_Fs, p.rf_decim, p.audio_decim, p.audio_upsamp, p.rf_taps,
+                                                   p.audio_taps, p.stereo_taps, channels)
+        return rp
 
 
 class RefPipeline:

@@ -79,7 +79,7 @@ def main():
     save("pipe_mode0.npz", **g2)
 
     # ---- G3 synthetic multi-block streams, all modes, mono + stereo -------
-    NBLK = 2
+    NBLK = 3
     inputs = {}
     for mode in range(4):
         p = o.mode_params(mode, 101, 101, 101)
@@ -106,7 +106,7 @@ def main():
         p = o.mode_params(0, rf_t, au_t, 101)
         pr = r.pipeline(0, 1, rf_t, au_t, 101)
         g = {}
-        for b in range(NBLK):
+        for b in range(2):
             out = pr.process(inputs["mode0"][b * p.block_bytes:(b + 1) * p.block_bytes])
             g[f"b{b}_audio"] = out["audio"]
             g[f"b{b}_demod_ht"] = ht(out["demod"])
@@ -196,5 +196,60 @@ def main():
          iq_sha256=np.frombuffer(hashlib.sha256(iqs.tobytes()).digest(), np.uint8))
 
 
+def spec_mode_params(o, U, D, channels_block_if=5000):
+    """BASELINE configs[2]: the course spec's fictive mode (doc/3dy4-project-2022.pdf p.3): 2.5 MS/s ->
+    250 kS/s -> 48 kS/s (U/D = 24/125) or 40 kS/s (4/25); project.cpp's parameter rules otherwise."""
+    p = o.mode_params(2, 101, 101, 101)           # a resampling mode as the template
+    p.rf_Fs, p.if_Fs, p.rf_decim = 2500000, 250000, 10
+    p.audio_upsamp, p.audio_decim = U, D
+    p.audio_Fs = 250000.0 * U / D
+    p.audio_taps = 101 * U
+    p.block_bytes = 2 * p.rf_decim * channels_block_if   # 5000 IF samples per block: 5000*U % D == 0 for both
+    return p
+
+
+def long_and_spec():
+    """G8: a 100-block (2.13 s) mode-0 stereo stream: snippets at checkpoints every 5 blocks and SHA-256 of
+    the whole left / right / NCO output, for the bit-exact mode and the error envelope of the fast one.
+    G9: configs[2] pipelines (3 blocks, mono and stereo)."""
+    o, r = Oracle(), Ref()
+    p = o.mode_params(0, 101, 101, 101)
+    nblk, every = 100, 5
+    iq = o.synth_fm_u8(p.block_bytes // 2 * nblk, rf_Fs=p.rf_Fs, seed=0x3D74)
+    pr = r.pipeline(0, 2, 101, 101, 101)
+    L, R, P = [], [], []
+    g = {"nblk": np.array([nblk]), "every": np.array([every]), "seed": np.array([0x3D74]),
+         "iq_sha256": np.frombuffer(hashlib.sha256(iq.tobytes()).digest(), np.uint8)}
+    for b in range(nblk):
+        out = pr.process(iq[b * p.block_bytes:(b + 1) * p.block_bytes])
+        L.append(out["audio_l"]); R.append(out["audio_r"]); P.append(pr.intermediate("pll")[1:])
+        if b % every == 0:
+            g[f"b{b}_audio_l"], g[f"b{b}_audio_r"] = out["audio_l"][:256], out["audio_r"][:256]
+            g[f"b{b}_pll"] = pr.intermediate("pll")[:257]
+    for k, v in (("audio_l", L), ("audio_r", R), ("pll", P)):
+        g[f"{k}_sha256"] = np.frombuffer(hashlib.sha256(np.concatenate(v).tobytes()).digest(), np.uint8)
+    g["audio_l_tail"], g["audio_r_tail"] = L[-1][-256:], R[-1][-256:]
+    save("stereo_long_mode0.npz", **g)
+
+    for U, D in ((4, 25), (24, 125)):
+        sp = spec_mode_params(o, U, D)
+        iqs = o.synth_fm_u8(sp.block_bytes // 2 * 3, rf_Fs=sp.rf_Fs, seed=0x3D74 + 100 + U)
+        for ch in (1, 2):
+            pr = r.pipeline_params(sp, ch)
+            g = {"block_bytes": np.array([sp.block_bytes]), "nblk": np.array([3]), "seed": np.array([0x3D74 + 100 + U])}
+            for b in range(3):
+                out = pr.process(iqs[b * sp.block_bytes:(b + 1) * sp.block_bytes])
+                g[f"b{b}_audio_l"] = out["audio_l"]
+                if ch == 2:
+                    g[f"b{b}_audio_r"] = out["audio_r"]
+                    g[f"b{b}_pll_ht"] = ht(pr.intermediate("pll"))
+                g[f"b{b}_demod_ht"] = ht(out["demod"])
+            save(f"spec_mode_{U}_{D}_ch{ch}.npz", **g)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "long":
+        long_and_spec()
+    else:
+        main()
+        long_and_spec()

@@ -37,9 +37,17 @@ def test_bench_json_contract(fmrx):
     r = out["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.05 < r["frac"] < 1.0
-    assert r["avg_launch_ms"] > 0 and r["launches_timed"] >= 2
+    assert r["avg_launch_ms"] > 0 and r["launches_timed"] == 8
+    assert r["algorithmic_bytes_per_sample"] == 2.04 and (r["traffic"] is None or "NOT measured in this run" in r["traffic_source"])
+    assert r["avg_launch_ms"] <= out["ms_per_step"] * 1.02          # the kernel cannot take longer than the step it is in
     c = out["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 1 and c["unit"] == "MS/s" and c["sample"]
     # value is whole-job throughput of exactly `steps` steps: consistent with ms_per_step
     assert abs(out["value"] - out["config"]["samples_per_step_per_gpu"] / (out["ms_per_step"] * 1e-3) / 1e6) / out["value"] < 0.01
     assert out["north_star_form"]["fe_variant"] == "valu" and out["north_star_form"]["value"] > 0
+    for k in ("two_kernel_path", "s1_if_only_mfma", "s1_if_only_valu", "mode1_mono", "mode2_mono", "mode3_mono", "mode0_stereo"):
+        g = out["legs"][k]
+        assert g["value"] > 0 and 0 < g["frac"] < 1 and g["algorithmic_bytes_per_sample"] >= 2.0, (k, g)
+    assert out["legs"]["small_block"]["us_per_block"] > 0
+    assert out["config"]["fmrx_env"] == []
+    assert "two_thread_pipeline" in c

@@ -27,9 +27,8 @@ def test_shim_compiles_and_fails_loudly_without_gpu(fmrx, oracle, tmp_path):
     if fmrx.device_count() > 0:
         pytest.skip("a GPU is present")
     iq = oracle.synth_fm_u8(51200)
-    iq.tofile(tmp_path / "in.u8")
-    r = subprocess.run([str(exe), str(tmp_path / "in.u8"), str(tmp_path / "out.f32")], capture_output=True, text=True)
-    assert r.returncode == 2 and "no usable HIP device" in r.stdout
+    r = subprocess.run([str(exe), str(tmp_path / "out.f32")], input=iq.tobytes(), capture_output=True)
+    assert r.returncode == 2 and b"no usable HIP device" in r.stdout
     assert not (tmp_path / "out.f32").exists()
 
 
@@ -37,8 +36,7 @@ def test_shim_compiles_and_fails_loudly_without_gpu(fmrx, oracle, tmp_path):
 def test_shim_chain_matches_oracle(fmrx, oracle, tmp_path):
     exe = _build(tmp_path)
     iq = oracle.synth_fm_u8(51200)
-    iq.tofile(tmp_path / "in.u8")
-    r = subprocess.run([str(exe), str(tmp_path / "in.u8"), str(tmp_path / "out.f32")], capture_output=True, text=True)
+    r = subprocess.run([str(exe), str(tmp_path / "out.f32")], input=iq.tobytes(), capture_output=True)
     assert r.returncode == 0, r.stdout + r.stderr
     got = np.fromfile(tmp_path / "out.f32", np.float32)
     want = oracle.pipeline(0, 1).process(iq)["audio"]

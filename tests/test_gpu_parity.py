@@ -136,7 +136,7 @@ def test_resampler_stage(fmrx, oracle, U, D, n):
 
 
 @pytest.mark.parametrize("U,D,n", [(147, 800, 800 * 500), (441, 3200, 3200 * 160), (4, 25, 25 * 20000)])
-def test_resampler_lds_table_kernel(fmrx, oracle, U, D, n, monkeypatch):
+def test_resampler_lds_table_kernel(fmrx, oracle, U, D, n):
     """Blocks with >= 65 536 outputs run the LDS-resident-table kernel (modes 2 / 3: one / two passes
     over the taps; the partial sum of a pass goes through the output as a float): bit-exact against
     the oracle and against the L2-table kernel, including the carried state."""
@@ -151,8 +151,11 @@ def test_resampler_lds_table_kernel(fmrx, oracle, U, D, n, monkeypatch):
     yo2, so2 = oracle.convolve_block_resample_fir(x[n:], h, so1, D, U)
     assert len(y1) >= 65536
     bits_equal(y1, yo1); bits_equal(y2, yo2); bits_equal(s2[U - 1::U], so2[U - 1::U])
-    monkeypatch.setenv("FMRX_RESAMPLE_L2", "1")
-    y3, _ = fmrx.convolveBlockResampleFIR(x[:n], h, st, D, U)
+    fmrx.set_option("resample_l2", 1)
+    try:
+        y3, _ = fmrx.convolveBlockResampleFIR(x[:n], h, st, D, U)
+    finally:
+        fmrx.set_option("resample_l2", 0)
     bits_equal(y3, y1)
 
 
@@ -201,20 +204,69 @@ def test_demod_allpass_mix_updown(fmrx, oracle, sig):
     bits_equal(l, sig[:1000] + sig[1000:2000]); bits_equal(r, sig[1000:2000] - sig[:1000])
 
 
+def test_device_libm_is_glibc(fmrx, oracle):
+    """The device build of csrc/glibc_libm.hpp (what fmPLL evaluates on the GPU) against the C library of
+    this host (what the reference's std::sin / std::cos / std::atan2 resolve to), bit for bit: 2^24
+    arguments spread over every exponent, the range the PLL lives in (trigArg 0 .. 2^23 rad, every
+    reduction path: |x| < 0.75, < 120, large), and atan2f on the PLL's own (v*-sin t, v*cos t) pairs,
+    the boundaries of atanf's argument reduction and the special values.  (The CPU build of the same
+    header is checked exhaustively in tests/test_libm_exact.py.)"""
+    rng = np.random.default_rng(235)
+    bits = rng.integers(0, 2**32, 1 << 23, dtype=np.uint64).astype(np.uint32)
+    x = np.concatenate([bits.view(np.float32),
+                        (rng.random(1 << 22) * 130.0 - 65.0).astype(np.float32),
+                        (rng.random(1 << 22) * 8388608.0).astype(np.float32),
+                        np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 0.75, 120.0, 119.99999, 0.7499999, 2.0**-12, 3.4e38], np.float32)])
+    for fn in ("sinf", "cosf"):
+        got, want = fmrx.deviceLibm(fn, x), oracle.libm(fn, x)
+        ok = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+        assert ok.all(), (fn, x[~ok][:5], got[~ok][:5], want[~ok][:5])
+    t = (rng.random(1 << 22) * 500000.0).astype(np.float32)
+    v = (rng.standard_normal(1 << 22) * 10.0 ** rng.integers(-9, 1, 1 << 22)).astype(np.float32)
+    y1, x1 = v * (-1 * oracle.libm("sinf", t)), v * oracle.libm("cosf", t)
+    y2, x2 = bits[: 1 << 22].view(np.float32), bits[1 << 22: 1 << 23].view(np.float32)
+    edges = np.array([0.4375, 0.6875, 1.1875, 2.4375, 1.0, 2.0**25, 2.0**-29], np.float32)
+    q = (edges[rng.integers(0, len(edges), 1 << 20)].view(np.uint32) + rng.integers(-40, 41, 1 << 20).astype(np.int64)).astype(np.uint32).view(np.float32)
+    x3 = (rng.random(1 << 20) + 0.5).astype(np.float32) * rng.choice(np.array([-1.0, 1.0], np.float32), 1 << 20)
+    sp = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 3.4e38, 1e-30, 1e30], np.float32)
+    ys = np.concatenate([y1, y2, q * x3, np.repeat(sp, len(sp))])
+    xs = np.concatenate([x1, x2, x3, np.tile(sp, len(sp))])
+    got, want = fmrx.deviceLibm("atan2f", ys, xs), oracle.libm("atan2f", ys, xs)
+    ok = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+    assert ok.all(), (ys[~ok][:5], xs[~ok][:5], got[~ok][:5], want[~ok][:5])
+
+
 def test_pll_stage(fmrx, oracle):
-    """Device sinf/cosf/atan2f differ from glibc by ulps and the loop feeds back:
-    NCO output within 2e-3 absolute over 6000 samples (measured 5e-4: one float32
-    ulp of trigArg ~ 1500 rad is 1.2e-4 rad, doubled by ncoScale), state within 1e-3."""
+    """fmPLL as a stage: the serial recurrence with glibc's sinf/cosf/atan2f restated on the device
+    (csrc/glibc_libm.hpp) -- BIT-EXACT against the compiled reference's golden output, the carried state
+    included, and against the oracle over a longer, noisy input with state carried across ragged blocks."""
     g = np.load(os.path.join(G, "edge.npz"))
     st = np.array([0, 0, 1, 0, 1, 0], np.float32)
     outs = []
     for blk in np.split(g["pll_in"], 3):
         y, st = fmrx.fmPLL(blk, st, 19e3, 240e3)
         outs.append(y)
-    got = np.concatenate(outs)
-    assert np.abs(got - g["pll_out"]).max() < 2e-3
-    assert np.abs(st[:5] - g["pll_state"][:5]).max() < 1e-3
-    assert st[5] == g["pll_state"][5] == 6000.0
+    bits_equal(np.concatenate(outs), g["pll_out"])
+    bits_equal(st, g["pll_state"])
+    rng = np.random.default_rng(19)
+    n = 120000
+    t = np.arange(n)
+    x = (0.08 * np.cos(2 * np.pi * 19.002e3 * t / 240e3 + 1.1) + 0.004 * rng.standard_normal(n)).astype(np.float32)
+    x[5000:5040] = 0.0                      # a drop-out: the signed-zero / y == 0 paths of atan2f
+    x[70000] = np.inf
+    sa = sb = np.array([0, 0, 1, 0, 1, 0], np.float32)
+    off = 0
+    for m in (1, 7, 5120, 30000, 64, 84808):
+        ya, sa = fmrx.fmPLL(x[off:off + m], sa, 19e3, 240e3, 2.0, 0.0, 0.01)
+        yb, sb = oracle.fm_pll(x[off:off + m], sb, 19e3, 240e3, 2.0, 0.0, 0.01)
+        ok = (ya.view(np.uint32) == yb.view(np.uint32)) | (np.isnan(ya) & np.isnan(yb))
+        assert ok.all(), (off, m, int(np.argmin(ok)))
+        assert ((sa.view(np.uint32) == sb.view(np.uint32)) | (np.isnan(sa) & np.isnan(sb))).all()
+        off += m
+    # other loop parameters (the RDS branch of the Python model uses ncoScale 0.5, a phase adjust and a wider loop)
+    ya, _ = fmrx.fmPLL(x[:20000], np.array([0, 0, 1, 0, 1, 0], np.float32), 19e3, 240e3, 0.5, 0.3, 0.02)
+    yb, _ = oracle.fm_pll(x[:20000], np.array([0, 0, 1, 0, 1, 0], np.float32), 19e3, 240e3, 0.5, 0.3, 0.02)
+    bits_equal(ya, yb)
 
 
 # ---------------------------------------------------------------------------
@@ -279,7 +331,7 @@ def test_front_end_dc_gain_and_silence(fmrx):
 
 @pytest.mark.parametrize("rf_taps", [13, 101, 151])
 @pytest.mark.parametrize("mode", [0, 1, 3])
-def test_front_end_matrix_core_kernel(fmrx, oracle, mode, rf_taps, monkeypatch):
+def test_front_end_matrix_core_kernel(fmrx, oracle, mode, rf_taps):
     """The pipeline's front end (int8 MFMA FIR + discriminator, kernels_fe_mfma.hip), all nine
     (taps, decim) shapes, over blocks of very different sizes: a few outputs, a ragged last tile,
     several waves (each starts with a tile it multiplies but does not store), and the IF stream on
@@ -294,6 +346,7 @@ def test_front_end_matrix_core_kernel(fmrx, oracle, mode, rf_taps, monkeypatch):
     iq = oracle.synth_fm_u8(sum(sizes) // 2, rf_Fs=p.rf_Fs, seed=1234 + mode)
     pl = fmrx.Pipeline(mode, 1, rf_taps=rf_taps, max_block_bytes=max(sizes))
     pv = fmrx.Pipeline(mode, 1, rf_taps=rf_taps, max_block_bytes=max(sizes))
+    pl.set_option("fe_variant", "mfma"); pv.set_option("fe_variant", "valu")
     po = oracle.pipeline(mode, 1, rf_taps, 101, 101)
     off = 0
     for i, nb in enumerate(sizes):
@@ -302,10 +355,9 @@ def test_front_end_matrix_core_kernel(fmrx, oracle, mode, rf_taps, monkeypatch):
         keep = i % 3 != 2
         pl.set_keep_intermediates(keep)
         out, ref = pl.process(blk), po.process(blk)
-        monkeypatch.setenv("FMRX_FE_VARIANT", "valu")
         pv.set_keep_intermediates(True)
-        pv.process(blk)
-        monkeypatch.delenv("FMRX_FE_VARIANT")
+        outv = pv.process(blk)
+        assert_audio_close(outv["audio"], ref["audio"], f"vector-ALU kernels, mode {mode} taps {rf_taps} block {nb}")
         if keep:
             for k in ("if_i", "if_q"):
                 got = pl.read_tap(k)
@@ -323,14 +375,12 @@ def test_front_end_matrix_core_kernel(fmrx, oracle, mode, rf_taps, monkeypatch):
 
 @pytest.mark.parametrize("rf_taps,au_taps", [(101, 101), (151, 101), (13, 13), (101, 13)])
 @pytest.mark.parametrize("mode", [0, 1])
-def test_fused_mono_kernel(fmrx, oracle, mode, rf_taps, au_taps, monkeypatch):
+def test_fused_mono_kernel(fmrx, oracle, mode, rf_taps, au_taps):
     """Modes 0/1 mono without intermediates = ONE kernel (front end, discriminator, audio FIR as f32
     MFMA, PCM): against the oracle, and against the two-kernel path on the same handle state (same
     carried state bit for bit: the IF arithmetic is the same integers; audio: two float32 summation
     orders of the same products).  Block sizes: one batch, partial batches, several waves, each
     starting with a tile it computes only for the audio history."""
-    if os.environ.get("FMRX_FE_VARIANT") == "valu":
-        pytest.skip("the suite was asked to run the vector-ALU kernels; the fused kernel is a matrix-core kernel")
     p = oracle.mode_params(mode, rf_taps, au_taps, 101)
     D, A = p.rf_decim, p.audio_decim
     unit = int(2 * D * np.lcm(A, 8))
@@ -338,16 +388,18 @@ def test_fused_mono_kernel(fmrx, oracle, mode, rf_taps, au_taps, monkeypatch):
     iq = oracle.synth_fm_u8(sum(sizes) // 2, rf_Fs=p.rf_Fs, seed=77 + mode)
     pf = fmrx.Pipeline(mode, 1, rf_taps=rf_taps, base_audio_taps=au_taps, max_block_bytes=max(sizes))
     pu = fmrx.Pipeline(mode, 1, rf_taps=rf_taps, base_audio_taps=au_taps, max_block_bytes=max(sizes))
+    for h in (pf, pu):
+        h.set_option("fe_variant", "mfma")
+    pf.set_option("fused_min_audio", 0)            # always the fused kernel
+    pu.set_option("fused_min_audio", 10**12)       # never
     po = oracle.pipeline(mode, 1, rf_taps, au_taps, 101)
     off = 0
     for nb in sizes:
         blk = iq[off:off + nb]
         off += nb
-        monkeypatch.setenv("FMRX_FUSED_MIN_AUDIO", "0")
         out = pf.process(blk)
         with pytest.raises(fmrx.FmrxError):
             pf.read_tap("demod")          # stayed on chip
-        monkeypatch.setenv("FMRX_FUSED_MIN_AUDIO", "1000000000000")
         outu = pu.process(blk)
         pu.read_tap("demod")
         ref = po.process(blk)
@@ -355,17 +407,15 @@ def test_fused_mono_kernel(fmrx, oracle, mode, rf_taps, au_taps, monkeypatch):
         assert_pcm_close(out["pcm16"], oracle.pcm16(ref["audio"]))
         assert np.abs(out["audio"] - outu["audio"]).max() <= 2e-6
         bits_equal(pf.get_state(), pu.get_state(), f"carried state after block {nb}")
-    monkeypatch.delenv("FMRX_FUSED_MIN_AUDIO")
 
 
 def test_fused_mono_kernel_many_batches_per_wave(fmrx, oracle):
     """A block large enough that every wave of the fused kernel owns several audio batches (the
     bench's regime), against the oracle; plus silence -> exact zeros."""
-    if os.environ.get("FMRX_FE_VARIANT") == "valu":
-        pytest.skip("the suite was asked to run the vector-ALU kernels; the fused kernel is a matrix-core kernel")
     n = 34 * 1_024_000
     iq = oracle.synth_fm_u8(n, seed=5150)
     pl = fmrx.Pipeline(0, 1, max_block_bytes=2 * n)
+    pl.set_option("fe_variant", "mfma")
     out = pl.process(iq)
     ref = oracle.pipeline(0, 1).process(iq)
     assert_audio_close(out["audio"], ref["audio"], "fused, 34 x 1,024,000 samples in one call")
@@ -379,14 +429,11 @@ def test_fused_mono_kernel_many_batches_per_wave(fmrx, oracle):
 
 
 @pytest.mark.parametrize("mode", [0, 1])
-def test_random_block_sizes_hand_state_between_kernels(fmrx, oracle, mode, monkeypatch):
+def test_random_block_sizes_hand_state_between_kernels(fmrx, oracle, mode):
     """40 blocks of random sizes (1 ... 3000 units) through one handle: with the fused kernel enabled
     from 2048 audio samples up, consecutive blocks alternate between the fused kernel and the
     front-end + audio kernel pair, each picking up the other's carried state (byte history, last IF
     sample, discriminator tail).  Audio of every block against the oracle streaming the same blocks."""
-    if os.environ.get("FMRX_FE_VARIANT") == "valu":
-        pytest.skip("fused kernel is a matrix-core kernel")
-    monkeypatch.setenv("FMRX_FUSED_MIN_AUDIO", "2048")
     p = oracle.mode_params(mode, 101, 101, 101)
     unit = int(2 * p.rf_decim * np.lcm(p.audio_decim, 8))
     rng = np.random.default_rng(2024 + mode)
@@ -396,6 +443,7 @@ def test_random_block_sizes_hand_state_between_kernels(fmrx, oracle, mode, monke
     sizes = [unit * max(k, floor) for k in ks]
     iq = oracle.synth_fm_u8(sum(sizes) // 2, rf_Fs=p.rf_Fs, seed=99 + mode)
     pl = fmrx.Pipeline(mode, 1, max_block_bytes=max(sizes))
+    pl.set_option("fe_variant", "mfma"); pl.set_option("fused_min_audio", 2048)
     po = oracle.pipeline(mode, 1)
     off, n_fused, got, want = 0, 0, [], []
     for nb in sizes:
@@ -419,12 +467,18 @@ def _run_blocks(pl, iq, bb, nblk):
     return outs
 
 
+FE_VARIANTS = ["mfma", "valu"]   # matrix-core kernels (default) / vector-ALU kernels (the north star's "no MFMA" form)
+
+
+@pytest.mark.parametrize("fe", FE_VARIANTS)
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
-def test_mono_pipeline_vs_golden_and_oracle(fmrx, oracle, mode):
+def test_mono_pipeline_vs_golden_and_oracle(fmrx, oracle, mode, fe):
     iq = np.load(os.path.join(G, "synth_inputs.npz"))[f"mode{mode}"]
     g = np.load(os.path.join(G, f"synth_mode{mode}_ch1.npz"))
     bb, nblk = int(g["block_bytes"][0]), int(g["nblk"][0])
+    assert nblk >= 3
     pl = fmrx.Pipeline(mode, 1)
+    pl.set_option("fe_variant", fe)
     pl.set_keep_intermediates(True)     # the fused front end does not store IF I/Q unless asked
     po = oracle.pipeline(mode, 1)
     for b in range(nblk):
@@ -485,16 +539,20 @@ def test_real_signal_block(fmrx, oracle):
         bits_equal(out["audio"], g[f"{tag}_audio"]); bits_equal(out["pcm16"], g[f"{tag}_s16"])  # incl. wrapped samples
 
 
+@pytest.mark.parametrize("fe", FE_VARIANTS)
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
-def test_stereo_pipeline(fmrx, oracle, mode):
-    """RF_STEREO.  Everything up to the PLL input is held to the mono tolerances;
-    the NCO inherits the device-libm recurrence: 5e-3 absolute (measured <= 1e-3:
-    one float32 ulp of trigArg, which grows to ~1e4 rad, doubled by ncoScale);
-    audio L/R RMS error <= 1e-4 (measured 3e-6 .. 6e-6)."""
+def test_stereo_pipeline(fmrx, oracle, mode, fe):
+    """RF_STEREO through the specialised kernels, three reference-size blocks (the first 64 ms of a stream).
+    Everything up to the PLL input is held to the mono tolerances; the NCO is a float32 recurrence on
+    the grid of trigArg (<= 8e3 rad here: ulp 5e-4 rad, doubled by ncoScale), which the upstream ulps
+    move by isolated single steps: 5e-3 absolute; audio L/R RMS error <= 1e-4 (measured 3e-6 .. 6e-6).
+    Longer streams: test_stereo_error_envelope_long_stream / test_stereo_bit_exact_mode_long_stream."""
     iq = np.load(os.path.join(G, "synth_inputs.npz"))[f"mode{mode}"]
     g = np.load(os.path.join(G, f"synth_mode{mode}_ch2.npz"))
     bb, nblk = int(g["block_bytes"][0]), int(g["nblk"][0])
+    assert nblk >= 3
     pl, po = fmrx.Pipeline(mode, 2), oracle.pipeline(mode, 2)
+    pl.set_option("fe_variant", fe)
     for b in range(nblk):
         blk = iq[b * bb:(b + 1) * bb]
         out, ref = pl.process(blk), po.process(blk)
@@ -523,6 +581,95 @@ def test_stereo_pipeline(fmrx, oracle, mode):
         assert len(out["pcm16"]) == 2 * len(out["audio_l"])
         assert_pcm_close(out["pcm16"][0::2], fmrx.pcm16(out["audio_l"]))
         assert_pcm_close(out["pcm16"][1::2], fmrx.pcm16(out["audio_r"]))
+
+
+def _long_stereo_stream(oracle):
+    g = np.load(os.path.join(G, "stereo_long_mode0.npz"))
+    p = oracle.mode_params(0, 101, 101, 101)
+    iq = oracle.synth_fm_u8(p.block_bytes // 2 * int(g["nblk"][0]), rf_Fs=p.rf_Fs, seed=int(g["seed"][0]))
+    assert hashlib.sha256(iq.tobytes()).digest() == g["iq_sha256"].tobytes()
+    return g, p, iq
+
+
+@pytest.mark.parametrize("block_bytes", [102400, 2 * 1024000], ids=["reference-size blocks", "1,024,000-sample blocks"])
+def test_stereo_bit_exact_mode_long_stream(fmrx, oracle, block_bytes):
+    """The bit-exact mode (set_force_generic: every stage in the reference's float32 evaluation order, fmPLL as
+    the serial recurrence with glibc's sinf/cosf/atan2f) over 100 reference blocks = 2.13 s of stereo stream,
+    cut as the reference cuts it and as 1,024,000-sample blocks: left, right and the NCO output are the
+    COMPILED REFERENCE's, bit for bit, all 102 400 audio samples and 512 000 NCO samples (SHA-256 and the
+    checkpoint snippets of tests/golden/stereo_long_mode0.npz; nothing from the oracle is involved)."""
+    g, p, iq = _long_stereo_stream(oracle)
+    pl = fmrx.Pipeline(0, 2, max_block_bytes=block_bytes)
+    pl.set_force_generic(True)
+    L, R, P = [], [], []
+    for o in range(0, len(iq), block_bytes):
+        out = pl.process(iq[o:o + block_bytes])
+        L.append(out["audio_l"]); R.append(out["audio_r"]); P.append(pl.read_tap("pll")[1:])
+    L, R, P = np.concatenate(L), np.concatenate(R), np.concatenate(P)
+    every = int(g["every"][0])
+    for b in range(0, int(g["nblk"][0]), every):
+        bits_equal(L[1024 * b:1024 * b + 256], g[f"b{b}_audio_l"], f"left, reference block {b}")
+        bits_equal(R[1024 * b:1024 * b + 256], g[f"b{b}_audio_r"], f"right, reference block {b}")
+        bits_equal(P[5120 * b:5120 * b + 256], g[f"b{b}_pll"][1:], f"NCO, reference block {b}")
+    for k, v in (("audio_l", L), ("audio_r", R), ("pll", P)):
+        assert hashlib.sha256(v.tobytes()).digest() == g[f"{k}_sha256"].tobytes(), k
+
+
+def stereo_error_envelope(got, want, window):
+    """RMS error per window of `window` samples -> array."""
+    n = len(want) // window * window
+    d = (np.asarray(got[:n], np.float64) - np.asarray(want[:n], np.float64)).reshape(-1, window)
+    return np.sqrt(np.mean(d * d, axis=1))
+
+
+def trig_arg_ulp(t_seconds, if_Fs=240e3, freq=19e3):
+    """ulp of fmPLL's float32 trigArg (src/filter.cpp:66) t seconds into a stream."""
+    ta = 2 * np.pi * freq / if_Fs * np.maximum(if_Fs * np.asarray(t_seconds, np.float64), 1.0)
+    return 2.0 ** (np.floor(np.log2(ta)) - 23)
+
+
+# Envelope of the specialised (fast) stereo path against the reference, stated up front:
+#   * while the stream is short enough for the float32 grid of trigArg to be finer than the bound
+#     (t < 0.13 s: trigArg < 2^14 rad, ulp < 1e-3 rad), audio RMS error <= 1e-4 (the north-star bound);
+#   * afterwards the reference's own recurrence is chaotic on that grid (kernels_pll.hip, DESIGN.md 2):
+#     ANY ulp-level difference upstream of the PLL -- here the specialised kernels' summation order --
+#     puts the NCO on a different sequence of grid points, and the audio error sits at a fraction of
+#     ulp(trigArg(t)): bound 0.25 ulp(trigArg(t)) per 0.1 s window (measured 0.05 .. 0.15; the oracle
+#     against itself with ONE input sample moved by one ulp measures the same, profiles/round2/
+#     stereo_error_vs_time.txt).  Beyond 2^24 IF samples (70 s) the reference's trigOffset stops counting.
+ENVELOPE_FACTOR = 0.25
+
+
+def test_stereo_error_envelope_long_stream(fmrx, oracle):
+    """The specialised stereo path (matrix-core front end, packed band-pass pair, parallel-in-time PLL) over
+    2.13 s of stream fed as 1,024,000-sample blocks, against the oracle for the WHOLE stream: the error per
+    0.1 s window stays inside the envelope stated above, left and right; the mono sum (L+R)/2, which does
+    not pass through the PLL, stays within the mono tolerance throughout."""
+    g, p, iq = _long_stereo_stream(oracle)
+    bb = 2 * 1024000
+    pl, po = fmrx.Pipeline(0, 2, max_block_bytes=bb), oracle.pipeline(0, 2)
+    L, R, Lo, Ro = [], [], [], []
+    for o in range(0, len(iq), bb):
+        out = pl.process(iq[o:o + bb])
+        L.append(out["audio_l"]); R.append(out["audio_r"])
+    for o in range(0, len(iq), p.block_bytes):
+        ref = po.process(iq[o:o + p.block_bytes])
+        Lo.append(ref["audio_l"]); Ro.append(ref["audio_r"])
+    L, R, Lo, Ro = (np.concatenate(v) for v in (L, R, Lo, Ro))
+    assert hashlib.sha256(Lo.tobytes()).digest() == g["audio_l_sha256"].tobytes()   # the oracle IS the reference here
+    win = 4800                                                                       # 0.1 s of 48 kHz audio
+    t_end = (np.arange(len(Lo) // win) + 1) * 0.1
+    bound = np.maximum(AUDIO_ABS_RMS, ENVELOPE_FACTOR * trig_arg_ulp(t_end))
+    for name, a, b in (("left", L, Lo), ("right", R, Ro)):
+        env = stereo_error_envelope(a, b, win)
+        print(name, "rms error per 0.1 s:", " ".join(f"{e:.1e}" for e in env))
+        print(name, "in units of ulp(trigArg):", " ".join(f"{e / u:.2f}" for e, u in zip(env, trig_arg_ulp(t_end))))
+        assert (env <= bound).all(), (name, env, bound)
+        assert env[0] <= AUDIO_ABS_RMS
+    mono = stereo_error_envelope((L.astype(np.float64) + R) / 2, (Lo.astype(np.float64) + Ro) / 2, win)
+    assert mono.max() <= 2e-6, mono.max()
+    rep, dp, di = pl.pll_diagnostics()
+    assert rep == 0, "a clean locked pilot: every segment of the parallel PLL merged"
 
 
 def test_stereo_parallel_pll_matches_serial(fmrx, oracle):
@@ -651,8 +798,9 @@ def test_state_round_trip(fmrx, oracle):
     bits_equal(st[202:302], ref["demod"][-100:])
 
 
+@pytest.mark.parametrize("fe", FE_VARIANTS)
 @pytest.mark.parametrize("channels", [1, 2])
-def test_ragged_block_sizes(fmrx, oracle, channels):
+def test_ragged_block_sizes(fmrx, oracle, channels, fe):
     """Block sizes the reference never uses: tiny blocks, sizes that are not 16-byte multiples
     (the front end then runs its generic kernel), alternating with large ones so specialised
     and generic kernels hand the carried state back and forth."""
@@ -660,6 +808,7 @@ def test_ragged_block_sizes(fmrx, oracle, channels):
     total = sum(sizes)
     iq = oracle.synth_fm_u8(total // 2, seed=31)
     pl = fmrx.Pipeline(0, channels, max_block_bytes=max(sizes))
+    pl.set_option("fe_variant", fe)
     po = oracle.pipeline(0, channels)
     off = 0
     for nb in sizes:
@@ -742,3 +891,109 @@ def test_cli_stdin_stdout(fmrx, oracle):
     assert rms(lr[0::2] / 16384.0 - L) <= 1e-3 and rms(lr[1::2] / 16384.0 - R) <= 1e-3
     r = subprocess.run([exe, "1", "--compat-exit"], input=iq[:61440 * 2].tobytes(), capture_output=True)
     assert r.returncode == 1 and len(r.stdout) == 2 * 2 * 1024   # the reference's exit status at EOF
+
+
+def _cli(fmrx, *args, data):
+    exe = os.path.join(os.path.dirname(fmrx.LIB_PATH), "fmrx_project")
+    r = subprocess.run([exe, *args], input=data.tobytes(), capture_output=True)
+    assert r.returncode == 0, r.stderr
+    return np.frombuffer(r.stdout, np.int16)
+
+
+@pytest.mark.parametrize("mode", [2, 3])
+@pytest.mark.parametrize("channels", [1, 2])
+def test_cli_resampling_modes(fmrx, oracle, mode, channels):
+    """`fmrx_project 2|3 [1|2]` (src/project.cpp:425-426 mode table, :56-57 block size): 44.1 kHz output through
+    the rational resampler, 5 reference-size blocks + a partial one on stdin, s16 on stdout against the oracle
+    streaming the same blocks: mono within 1 LSB; stereo within the first-blocks tolerance of the PLL path."""
+    p = oracle.mode_params(mode)
+    nblk = 5
+    iq = oracle.synth_fm_u8(p.block_bytes // 2 * nblk + 500, rf_Fs=p.rf_Fs, seed=0x3D74 + mode)
+    s16 = _cli(fmrx, str(mode), str(channels), data=iq)
+    po = oracle.pipeline(mode, channels)
+    outs = [po.process(iq[b * p.block_bytes:(b + 1) * p.block_bytes]) for b in range(nblk)]
+    n_a = len(outs[0]["audio_l"])
+    assert n_a == {2: 1029, 3: 3087}[mode] and len(s16) == channels * nblk * n_a     # partial block dropped, queue drained
+    L = np.concatenate([o["audio_l"] for o in outs])
+    if channels == 1:
+        assert_pcm_close(s16, oracle.pcm16(L))
+    else:
+        R = np.concatenate([o["audio_r"] for o in outs])
+        assert rms(s16[0::2] / 16384.0 - L) <= 1e-4 and rms(s16[1::2] / 16384.0 - R) <= 1e-4
+    # the same stream, 3 reference blocks per device call: EOF falls inside a chunk (5 = 3 + 2), and the two whole
+    # reference blocks of the short chunk must still come out (only the trailing partial reference block is dropped)
+    s16k = _cli(fmrx, str(mode), str(channels), "--blocks-per-call", "3", data=iq)
+    assert len(s16k) == len(s16)
+    if channels == 1:
+        assert_pcm_close(s16k, oracle.pcm16(L))
+    else:
+        assert rms(s16k[0::2] / 16384.0 - L) <= 1e-4
+
+
+def test_cli_presets_and_exact_mode(fmrx, oracle):
+    """--like project / --like threadMonoOnly select the tap counts the two reference binaries ship with
+    (13/13/13 and 151/101); --exact is the bit-exact mode: stereo s16 equal to the oracle's sample for
+    sample (12 reference blocks, fed 5 per call: 5 + 5 + 2)."""
+    p = oracle.mode_params(0)
+    iq = oracle.synth_fm_u8(51200 * 12 + 77, seed=0x3D74)
+    g = np.load(os.path.join(G, "tmo_mode0.npz"))
+    s16 = _cli(fmrx, "0", "--like", "threadMonoOnly", data=iq)
+    assert_pcm_close(s16[: len(g["s16"])], g["s16"])                       # the reference BINARY's captured stdout
+    s16 = _cli(fmrx, "0", "1", "--like", "project", data=iq)
+    po = oracle.pipeline(0, 1, 13, 13, 13)
+    want = np.concatenate([po.process(iq[b * 102400:(b + 1) * 102400])["audio"] for b in range(12)])
+    assert_pcm_close(s16, oracle.pcm16(want))
+    lr = _cli(fmrx, "0", "2", "--exact", "--blocks-per-call", "5", data=iq)
+    po = oracle.pipeline(0, 2)
+    outs = [po.process(iq[b * 102400:(b + 1) * 102400]) for b in range(12)]
+    bits_equal(lr[0::2], oracle.pcm16(np.concatenate([o["audio_l"] for o in outs])))
+    bits_equal(lr[1::2], oracle.pcm16(np.concatenate([o["audio_r"] for o in outs])))
+
+
+def spec_mode_params(fmrx, U, D):
+    """BASELINE configs[2]: the course spec's fictive mode (doc/3dy4-project-2022.pdf p.3): 2.5 MS/s -> 250 kS/s ->
+    48 kS/s (U/D = 24/125) or 40 kS/s (4/25), project.cpp's parameter rules otherwise (audio_taps = 101 U)."""
+    p = fmrx.modeParams(2)
+    p.rf_Fs, p.if_Fs, p.rf_decim = 2500000, 250000, 10
+    p.audio_upsamp, p.audio_decim = U, D
+    p.audio_Fs = 250000.0 * U / D
+    p.audio_taps = 101 * U
+    p.block_bytes = 2 * p.rf_decim * 5000
+    return p
+
+
+@pytest.mark.parametrize("fe", FE_VARIANTS)
+@pytest.mark.parametrize("U,D", [(4, 25), (24, 125)])
+@pytest.mark.parametrize("channels", [1, 2])
+def test_spec_mode_pipeline(fmrx, oracle, U, D, channels, fe):
+    """BASELINE configs[2] end to end: 2.5 MS/s -> 250 kS/s -> 40 kS/s (4/25) and -> 48 kS/s (24/125) through
+    fmrx_pipeline_create with explicit parameters (front end decimate 10, polyphase resampler, optional stereo):
+    three 50,000-sample blocks against the COMPILED REFERENCE's golden output (tests/golden/spec_mode_*.npz),
+    then the same stream as ONE large call (the LDS-resident-table resampler) against the oracle."""
+    g = np.load(os.path.join(G, f"spec_mode_{U}_{D}_ch{channels}.npz"))
+    sp = spec_mode_params(fmrx, U, D)
+    bb = int(g["block_bytes"][0])
+    assert bb == sp.block_bytes
+    iq = oracle.synth_fm_u8(bb // 2 * 3, rf_Fs=2.5e6, seed=int(g["seed"][0]))
+    pl = fmrx.Pipeline(params=sp, channels=channels, max_block_bytes=bb)
+    pl.set_option("fe_variant", fe)
+    for b in range(3):
+        out = pl.process(iq[b * bb:(b + 1) * bb])
+        assert len(out["audio_l"]) == 5000 * U // D
+        assert_audio_close(out["audio_l"], g[f"b{b}_audio_l"], f"spec mode {U}/{D} ch{channels} block {b}")
+        if channels == 2:
+            assert_audio_close(out["audio_r"], g[f"b{b}_audio_r"], f"right, block {b}")
+        assert rel_rms(pl.read_tap("demod")[:256], g[f"b{b}_demod_ht"][:256]) <= 1e-5
+    # one large call: 80 blocks' worth (>= 65 536 outputs for 4/25 needs 410 k IF samples: 90 blocks)
+    if channels == 1 and fe == "mfma":
+        nbig = 90
+        big = oracle.synth_fm_u8(bb // 2 * nbig, rf_Fs=2.5e6, seed=5)
+        plb = fmrx.Pipeline(params=sp, channels=1, max_block_bytes=bb * nbig)
+        op = oracle.mode_params(2)
+        for k in ("rf_Fs", "if_Fs", "rf_decim", "audio_upsamp", "audio_decim", "audio_Fs", "audio_taps", "block_bytes"):
+            setattr(op, k, getattr(sp, k))
+        po = oracle.pipeline_params(op, 1)
+        want = np.concatenate([po.process(big[b * bb:(b + 1) * bb])["audio"] for b in range(nbig)])
+        got = plb.process(big)["audio"]
+        assert len(got) == len(want) >= 65536
+        assert_audio_close(got, want, f"spec mode {U}/{D}, {nbig} blocks in one call")

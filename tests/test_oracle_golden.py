@@ -179,3 +179,54 @@ def test_psd_golden(oracle):
         bits_equal(f, g[f"{k}_freq"]); bits_equal(p, g[f"{k}_psd"])
     assert int(np.argmax(g["tone_psd"])) == 32          # 3 kHz at 48 kHz / 512 per bin
     assert np.all(np.diff(g["tone_freq"]) == np.float32(93.75))
+
+
+def test_long_stereo_stream(oracle):
+    """100 reference blocks (2.13 s) of mode-0 stereo through the oracle, block by block, against the
+    compiled reference's output: snippets at the checkpoints and SHA-256 of the WHOLE left / right / NCO
+    streams -- the pilot PLL recurrence (glibc sinf/cosf/atan2f inside) included, bit for bit."""
+    g = load("stereo_long_mode0.npz")
+    nblk, every = int(g["nblk"][0]), int(g["every"][0])
+    p = oracle.mode_params(0, 101, 101, 101)
+    iq = oracle.synth_fm_u8(p.block_bytes // 2 * nblk, rf_Fs=p.rf_Fs, seed=int(g["seed"][0]))
+    assert hashlib.sha256(iq.tobytes()).digest() == g["iq_sha256"].tobytes()
+    po = oracle.pipeline(0, 2)
+    L, R, P = [], [], []
+    for b in range(nblk):
+        out = po.process(iq[b * p.block_bytes:(b + 1) * p.block_bytes])
+        L.append(out["audio_l"]); R.append(out["audio_r"]); P.append(po.intermediate("pll")[1:])
+        if b % every == 0:
+            bits_equal(out["audio_l"][:256], g[f"b{b}_audio_l"]); bits_equal(out["audio_r"][:256], g[f"b{b}_audio_r"])
+            bits_equal(po.intermediate("pll")[:257], g[f"b{b}_pll"])
+    for k, v in (("audio_l", L), ("audio_r", R), ("pll", P)):
+        assert hashlib.sha256(np.concatenate(v).tobytes()).digest() == g[f"{k}_sha256"].tobytes(), k
+
+
+def spec_mode_params(oracle, U, D):
+    """BASELINE configs[2] (doc/3dy4-project-2022.pdf p.3): 2.5 MS/s -> 250 kS/s -> 48 kS/s (24/125) or 40 kS/s (4/25)."""
+    p = oracle.mode_params(2, 101, 101, 101)
+    p.rf_Fs, p.if_Fs, p.rf_decim = 2500000, 250000, 10
+    p.audio_upsamp, p.audio_decim = U, D
+    p.audio_Fs = 250000.0 * U / D
+    p.audio_taps = 101 * U
+    p.block_bytes = 2 * p.rf_decim * 5000
+    return p
+
+
+@pytest.mark.parametrize("U,D", [(4, 25), (24, 125)])
+@pytest.mark.parametrize("ch", [1, 2])
+def test_spec_mode_pipeline(oracle, U, D, ch):
+    """configs[2] as a whole pipeline: the reference's graph at the course spec's 2.5 MS/s parameters."""
+    g = load(f"spec_mode_{U}_{D}_ch{ch}.npz")
+    sp = spec_mode_params(oracle, U, D)
+    assert int(g["block_bytes"][0]) == sp.block_bytes
+    iq = oracle.synth_fm_u8(sp.block_bytes // 2 * 3, rf_Fs=sp.rf_Fs, seed=int(g["seed"][0]))
+    po = oracle.pipeline_params(sp, ch)
+    for b in range(3):
+        out = po.process(iq[b * sp.block_bytes:(b + 1) * sp.block_bytes])
+        bits_equal(out["audio_l"], g[f"b{b}_audio_l"])
+        assert len(out["audio_l"]) == 5000 * U // D
+        bits_equal(ht(out["demod"]), g[f"b{b}_demod_ht"])
+        if ch == 2:
+            bits_equal(out["audio_r"], g[f"b{b}_audio_r"])
+            bits_equal(ht(po.intermediate("pll")), g[f"b{b}_pll_ht"])

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Stereo error vs stream time, cause by cause: the same 2.13 s mode-0 stereo stream
+through the GPU pipeline in four configurations, each against the oracle (= the compiled reference, bit for
+bit) for the whole stream, RMS error of the left channel per 0.1 s window, in absolute terms and in units of
+ulp(trigArg(t)):
+   fast / parallel   default: specialised kernels, parallel-in-time PLL, fast math (closed-form phase detector)
+   fast / serial     pll_mode 1: same math, serial recurrence               -> isolates the segment merge
+   fast / glibc      pll_mode 2: serial recurrence with glibc's functions   -> isolates the math library
+   bit-exact         set_force_generic: reference evaluation order upstream too -> must be 0
+Checker script (imports the oracle): lives under tests/.  Usage: python tests/tools/stereo_envelope.py [block_bytes]"""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.dirname(HERE), os.path.dirname(os.path.dirname(HERE))]
+from _oracle import Oracle  # noqa: E402
+
+fmrx = importlib.import_module("software-defined-radio_amd")
+
+
+def ulp(t):
+    ta = 2 * np.pi * 19e3 / 240e3 * np.maximum(240e3 * np.asarray(t, np.float64), 1.0)
+    return 2.0 ** (np.floor(np.log2(ta)) - 23)
+
+
+def main():
+    bb = int(sys.argv[1]) if len(sys.argv) > 1 else 2 * 1024000
+    nblk = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    o = Oracle()
+    p = o.mode_params(0, 101, 101, 101)
+    iq = o.synth_fm_u8(p.block_bytes // 2 * nblk, rf_Fs=p.rf_Fs, seed=0x3D74)
+    po = o.pipeline(0, 2)
+    Lo = np.concatenate([po.process(iq[k:k + p.block_bytes])["audio_l"] for k in range(0, len(iq), p.block_bytes)])
+    win = 4800
+    t_end = (np.arange(len(Lo) // win) + 1) * 0.1
+    rows = {}
+    for name, cfg in (("fast/parallel", {}), ("fast/serial", {"pll_mode": 1}), ("fast/glibc", {"pll_mode": 2}),
+                      ("valu/parallel", {"fe_variant": 1}), ("bit-exact", {"generic": 1})):
+        pl = fmrx.Pipeline(0, 2, max_block_bytes=bb)
+        for k, v in cfg.items():
+            if k == "generic":
+                pl.set_force_generic(True)
+            else:
+                pl.set_option(k, v)
+        t0 = time.perf_counter()
+        L = np.concatenate([pl.process(iq[k:k + bb])["audio_l"] for k in range(0, len(iq) // bb * bb, bb)])
+        dt = time.perf_counter() - t0
+        n = min(len(L), len(Lo)) // win * win
+        d = (L[:n].astype(np.float64) - Lo[:n]).reshape(-1, win)
+        rows[name] = (np.sqrt(np.mean(d * d, axis=1)), dt)
+    names = list(rows)
+    print(f"# mode 0 stereo, {nblk} reference blocks = {nblk * 51200 / 2.4e6:.2f} s, fed as {bb}-byte blocks; "
+          f"left-channel RMS error vs the oracle per 0.1 s window: absolute (in ulp(trigArg))")
+    print("t_end[s]  ulp(trigArg)  " + "  ".join(f"{n:>22s}" for n in names))
+    for i, t in enumerate(t_end[: len(rows[names[0]][0])]):
+        print(f"{t:7.1f}  {ulp(t):11.2e}  " + "  ".join(f"{rows[n][0][i]:12.2e} ({rows[n][0][i] / ulp(t):5.3f})" for n in names))
+    print("wall seconds incl. host copies: " + ", ".join(f"{n} {rows[n][1]:.2f}" for n in names))
+
+
+if __name__ == "__main__":
+    main()

@@ -30,7 +30,7 @@ res = {}
 outs = {}
 for rnd in range(ROUNDS):
     for v in ("mfma", "valu"):
-        os.environ["FMRX_FE_VARIANT"] = v
+        fmrx.set_option("fe_variant", v)
         for _ in range(3):
             plan.run_dev(iq.data_ptr(), n, hist.data_ptr(), d_if.data_ptr(), stream=s)
         torch.cuda.synchronize()

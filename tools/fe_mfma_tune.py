@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""A/B the matrix-core front end over (workgroups per CU, tiles in flight), one process, interleaved rounds."""
+"""A/B the matrix-core front end over (workgroups per CU, tiles in flight), one process, interleaved rounds.
+Needs the tuning build of the library (ablation kernels are not in the shipped libfmrx.so):
+    make -C software-defined-radio_amd/csrc TUNING=1 && FMRX_LIB=software-defined-radio_amd/lib/libfmrx_tuning.so python tools/fe_mfma_tune.py"""
 import importlib, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,12 +15,12 @@ pl = fmrx.Pipeline(0, 1, max_block_bytes=n_bytes)
 na = pl.n_audio(n_bytes)
 d_a = torch.empty(na, dtype=torch.float32, device="cuda"); d_p = torch.empty(na, dtype=torch.int16, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
-os.environ["FMRX_FUSED_MIN_AUDIO"] = "1000000000000"   # the S2 kernel, not the fused one
+pl.set_option("fused_min_audio", 10**12)   # the S2 kernel, not the fused one
 variants = sys.argv[1:] or ["23", "22", "24", "33", "43", "13"]
 res = {}
 for rnd in range(5):
     for v in variants:
-        os.environ["FMRX_FE_MFMA_TUNE"] = v
+        pl.set_option("fe_mfma_tune", int(v))
         pl.set_profiling(False)
         for _ in range(3):
             pl.process_dev(d_iq.data_ptr(), n_bytes, d_a.data_ptr(), d_p.data_ptr(), stream=s)

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""A/B variants of the fused mono kernel (FMRX_FUSED_TUNE), one process, interleaved rounds, after a settle phase."""
+"""A/B variants of the fused mono kernel (option fused_tune), one process, interleaved rounds, after a settle phase.
+Needs the tuning build of the library (ablation kernels are not in the shipped libfmrx.so):
+    make -C software-defined-radio_amd/csrc TUNING=1 && FMRX_LIB=software-defined-radio_amd/lib/libfmrx_tuning.so python tools/fused_tune.py"""
 import importlib, os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,7 +24,7 @@ run(3000)   # settle
 res = {}
 for rnd in range(5):
     for v in variants:
-        os.environ["FMRX_FUSED_TUNE"] = v
+        pl.set_option("fused_tune", int(v))
         run(20)
         t0 = time.perf_counter(); run(200); dt = (time.perf_counter() - t0) / 200 * 1e3
         res.setdefault(v, []).append(dt)
