@@ -13,6 +13,6 @@ step() {   # name, timeout, command...
   if [ $rc -ge 124 ]; then echo "killed: stopping"; exit $rc; fi
 }
 : > gpurun_out/r2a_steps.log
-step pytest 800 python -m pytest tests -m gpu -q -x --timeout 400 -p no:cacheprovider
+step pytest 800 python -m pytest tests -m gpu -q --timeout 400 -p no:cacheprovider
 step envelope 300 python tests/tools/stereo_envelope.py
 step bench 400 python bench.py --steps 20 --warmup 5
