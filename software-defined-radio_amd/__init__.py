@@ -44,24 +44,9 @@ if not os.path.exists(LIB_PATH):
 
 
 
-def _load_torch_first() -> None:
-    """torch wheels bundle their own libamdhip64.so.7 and libfmrx.so needs the same
-    soname from /opt/rocm; whichever is loaded first serves both.  torch -> libfmrx is
-    the order that works (bench.py); the other order hangs inside `import torch`.
-    So when torch is installed, import it before the library is loaded.  Set
-    FMRX_NO_TORCH=1 to skip this in a torch-free process."""
-    import importlib.util
-    import sys
-    if "torch" in sys.modules or os.environ.get("FMRX_NO_TORCH") == "1":
-        return
-    try:
-        if importlib.util.find_spec("torch") is not None:
-            import torch  # noqa: F401
-    except Exception:  # a broken torch install must not take the DSP library down with it
-        pass
-
-
-_load_torch_first()
+# libfmrx.so and PyTorch can be loaded in either order: the library records its HIP / HSA runtime dependencies
+# by the unversioned names torch's own libraries use, so ld.so maps ONE runtime whichever comes first
+# (csrc/Makefile; tests/test_load_order.py runs both orders on the GPU).
 lib = C.CDLL(LIB_PATH)
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")

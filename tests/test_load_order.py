@@ -45,7 +45,7 @@ print("OK", order, n, hip, hsa)
 
 
 def _run(order, gpu):
-    env = dict(os.environ, FMRX_NO_TORCH="1")
+    env = dict(os.environ)
     return subprocess.run([sys.executable, "-c", CHILD, order, LIB, "1" if gpu else "0"], capture_output=True, text=True,
                           timeout=300, env=env)
 
