@@ -75,6 +75,7 @@ FMRX_API int fmrx_set_device(int device);
  *   "resample_l2"      1 = the L2-table resampler kernel also for large calls
  *   "fe_wgs_per_cu"    cap on resident workgroups per CU of the front-end kernels (0 = auto)
  *   "pll_warmup", "pll_segment", "pll_head"   lane shape of the parallel-in-time PLL (-1 = built-in)
+ *   "pll_align"        1 = lanes of the parallel PLL start on a multiple of the loop's period (default), 0 = exactly pll_warmup early
  *   "pll_mode"         stereo PLL of the specialised pipeline: 0 = parallel in time, fast math (default),
  *                      1 = serial, fast math, 2 = serial, glibc's functions (cause-by-cause variants)
  *   "fused_tune", "fe_mfma_tune"              ablation kernels (timing only, WRONG results): FMRX_EINVAL unless the

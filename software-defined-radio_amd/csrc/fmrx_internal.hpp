@@ -48,6 +48,7 @@ struct Options {
     int fe_wgs_per_cu = 0;         // "fe_wgs_per_cu" / FMRX_FE_WGS_PER_CU: cap on resident workgroups per CU of the front-end kernels (0 = auto)
     int pll_warmup = -1;           // "pll_warmup" / FMRX_PLL_WARMUP: warm-up samples per lane of the parallel PLL (-1 = built-in)
     int pll_segment = -1;          // "pll_segment" / FMRX_PLL_SEGMENT: samples per lane (-1 = built-in)
+    int pll_align = 0;             // "pll_align" / FMRX_PLL_ALIGN: 1 = lanes start on a multiple of the loop's period, 0 = exactly W early (default)
     int pll_head = -1;             // "pll_head" / FMRX_PLL_HEAD: samples of a stream's first call walked serially (-1 = built-in)
     int pll_mode = 0;              // "pll_mode" / FMRX_PLL_MODE: stereo PLL of the specialised pipeline: 0 = parallel in time, fast math
                                    //   (default); 1 = serial, fast math; 2 = serial, glibc math (the cause-by-cause variants of DESIGN 2)
@@ -110,7 +111,9 @@ int fe_plan_init(FePlan &pl, const float *h, int taps, int decim);
 int fe_mfma_plan_init(FePlan &pl, const float *h, int taps, int decim);
 bool fe_mfma_available(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist);
 int fe_mfma_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist, const float *d_prev,
-                   float *d_demod, float *d_if, float *d_prev_out, uint8_t *d_hist_next, const Options &o, hipStream_t stream);
+                   float *d_demod, float *d_if, float *d_prev_out, uint8_t *d_hist_next, const Options &o, hipStream_t stream,
+                   const float *d_dhist_src = nullptr, float *d_dhist_dst = nullptr, int dhist_n = 0);
+// (d_dhist_src -> d_dhist_dst, dhist_n floats: the discriminator history copied in front of this block's output by the kernel itself)
 // d_hist: hist_bytes bytes whose LAST 2*(taps-1) hold the previous samples.
 // Writes n_samples/decim float2 (I,Q) to d_if.
 int fe_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist, float *d_if,
@@ -181,6 +184,13 @@ int bpf_pair_plan_init(BpfPairPlan &pl, const float *h_stereo, const float *h_ca
 int bpf_pair_launch(const BpfPairPlan &pl, const float *d_x, size_t n, float *d_st, float *d_car, hipStream_t stream,
                     bool force_generic);
 
+// everything behind the PLL of modes 0/1 in one kernel: mixer, both audio FIRs (mono branch on the all-passed
+// discriminator output, stereo branch on the mixer output), L/R combine, PCM (kernels_stereo.hip)
+bool stereo_out_available(int taps, int decim);
+int stereo_out_launch(const float *d_demod, const float *d_bpf, const float *d_nco, const float *d_mix_tail_in,
+                      float *d_mix_tail_out, int hm, size_t n_if, int delay, const float *d_h, int taps, int decim, float *d_mono,
+                      float *d_st, float *d_left, float *d_right, int16_t *d_pcm, int wrap, float *d_mixer, hipStream_t stream);
+
 // ---- generic kernels (kernels_generic.hip) ----------------------------------
 // y[k] = sum_{n<taps} h[n]*x[decim*k - n], sequential mul+add in n (bit-compatible
 // with the reference's evaluation order).  x[-(taps-1)..-1] must be readable.
@@ -212,7 +222,8 @@ int k_fm_pll(const float *d_in, size_t n, float *d_out, float *d_state, float fr
 // within the merge tolerance below, serial repair where the loop was not locked.  Agrees with the serial
 // trajectory to within the float32 grid of trigArg, not bit for bit (kernels_pll.hip).  d_scratch:
 // pll_parallel_scratch_floats(n) floats; d_scratch[2] (as u32) counts segments that needed a repair (diagnostic).
-constexpr int kPllSegment = 512, kPllWarmup = 768;
+// lane shape: L samples per lane, started at the last multiple of the loop's period that is >= W samples early
+constexpr int kPllSegment = 64, kPllWarmup = 512, kPllSegmentMin = 32;
 constexpr int kPllHead = 1024;   // samples of a stream's first call walked serially (acquisition) before the lanes take over
 // merge tolerance between a lane's warmed-up state and the true state (see kernels_pll.hip)
 constexpr float kPllTolPhase = 1e-2f, kPllTolInteg = 1e-4f;

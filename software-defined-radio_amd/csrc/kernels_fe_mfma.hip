@@ -126,7 +126,8 @@ template <int T, int D, int MINB, int PF, int DBG = 0>
 __global__ __launch_bounds__(256, MINB) void fe_mfma_kernel(
     const uint8_t *__restrict__ x, const uint8_t *__restrict__ hist_end, long n_bytes, const i4 *__restrict__ a_img,
     float scale_lo, const float2 *__restrict__ prev_in, float *__restrict__ demod, float *__restrict__ y_if,
-    float2 *__restrict__ prev_out, long n_out, int n_tiles, uint8_t *__restrict__ hist_next, int hist_bytes)
+    float2 *__restrict__ prev_out, long n_out, int n_tiles, uint8_t *__restrict__ hist_next, int hist_bytes,
+    const float *__restrict__ dhist_src, float *__restrict__ dhist_dst, int dhist_n)
 {
     using C = MfCfg<T, D, PF>;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
@@ -142,6 +143,10 @@ __global__ __launch_bounds__(256, MINB) void fe_mfma_kernel(
     // src/filter.cpp:182-187): one wave copies them; host guarantees n_bytes >= hist_bytes
     if (hist_next && tile == 0)
         for (int i = lane; i < hist_bytes; i += 64) hist_next[i] = x[n_bytes - hist_bytes + i];
+    // the discriminator history in front of this block's output (the previous block's tail lives in the other
+    // buffer): copied here so that the consumers of demod[-k] need no separate copy in front of them
+    if (dhist_dst && tile == 1)   // the second wave (wave 0 copies the byte history)
+        for (int i = lane; i < dhist_n; i += 64) dhist_dst[i] = dhist_src[i];
     if (tile >= n_tiles) return;
 
     // taps: KSTEPS x NDIG fragments, resident for the whole kernel
@@ -259,7 +264,8 @@ __global__ __launch_bounds__(256, MINB) void fe_mfma_kernel(
 
 template <int T, int D, int MINB = 2, int PF = 0, int DBG = 0>
 int launch_mfma(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist, const float *d_prev,
-                float *d_demod, float *d_if, float *d_prev_out, uint8_t *d_hist_next, const Options &o, hipStream_t stream)
+                float *d_demod, float *d_if, float *d_prev_out, uint8_t *d_hist_next, const Options &o, hipStream_t stream,
+                const float *d_dhist_src = nullptr, float *d_dhist_dst = nullptr, int dhist_n = 0)
 {
     using C = MfCfg<T, D, PF>;
     if (C::LEAD > pl.hist_bytes) return fail(FMRX_EINVAL, "fe_mfma: history too short");
@@ -273,7 +279,8 @@ int launch_mfma(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const u
     hipLaunchKernelGGL((fe_mfma_kernel<T, D, MINB, PF, DBG>), dim3(static_cast<unsigned>(grid)), dim3(256), 4 * C::RING, stream, d_iq,
                        d_hist + pl.hist_bytes, static_cast<long>(2 * n_samples), reinterpret_cast<const i4 *>(pl.a_img.p),
                        pl.scale_lo, reinterpret_cast<const float2 *>(d_prev), d_demod, d_if,
-                       reinterpret_cast<float2 *>(d_prev_out), n_out, static_cast<int>(n_tiles), d_hist_next, pl.hist_bytes);
+                       reinterpret_cast<float2 *>(d_prev_out), n_out, static_cast<int>(n_tiles), d_hist_next, pl.hist_bytes,
+                       d_dhist_src, d_dhist_dst, dhist_n);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FMRX_EHIP, "launch fe_mfma_kernel<%d,%d>: %s", T, D, hipGetErrorString(e));
     return FMRX_OK;
@@ -670,7 +677,8 @@ bool fe_mfma_available(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, 
 }
 
 int fe_mfma_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist, const float *d_prev,
-                   float *d_demod, float *d_if, float *d_prev_out, uint8_t *d_hist_next, const Options &o, hipStream_t stream)
+                   float *d_demod, float *d_if, float *d_prev_out, uint8_t *d_hist_next, const Options &o, hipStream_t stream,
+                   const float *d_dhist_src, float *d_dhist_dst, int dhist_n)
 {
     if (n_samples / pl.decim == 0) return FMRX_OK;
     if (!d_demod && !d_if) return fail(FMRX_EINVAL, "fe_mfma_launch: no output");
@@ -690,7 +698,8 @@ int fe_mfma_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, cons
 #endif
 #define X(T_, D_) \
     if (pl.taps == T_ && pl.decim == D_) \
-        return launch_mfma<T_, D_>(pl, d_iq, n_samples, d_hist, d_prev, d_demod, d_if, d_prev_out, d_hist_next, o, stream);
+        return launch_mfma<T_, D_>(pl, d_iq, n_samples, d_hist, d_prev, d_demod, d_if, d_prev_out, d_hist_next, o, stream, \
+                                   d_dhist_src, d_dhist_dst, dhist_n);
     FMRX_FE_MFMA_CASES(X)
 #undef X
     return fail(FMRX_EINVAL, "fe_mfma_launch: no kernel for taps=%d decim=%d", pl.taps, pl.decim);

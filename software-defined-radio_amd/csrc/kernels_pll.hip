@@ -71,9 +71,10 @@ struct PllState {
 
 enum PllMath { kExact = 0, kFast = 1 };
 
-// One step.  kExact: the reference's operations in its order, glibc's functions; s.last holds the
-// raw trigArg (the NCO output cosf(trigArg*ncoScale + phaseAdjust) is not part of the recurrence:
-// nco_out_kernel applies it afterwards).  kFast: see the file header; s.last is the NCO output.
+// One step of the recurrence.  Both forms leave the RAW trigArg in s.last: the NCO output
+// cosf(trigArg*ncoScale + phaseAdjust) is not part of the recurrence and is applied afterwards, in parallel,
+// by nco_out_kernel<MATH>.  kExact: the reference's operations in its order, glibc's functions.  kFast: see the
+// file header; the feedback pair (fbI, fbQ) is carried as the angle s.fr it is the cosine / sine of.
 template <int MATH>
 __device__ __forceinline__ void pll_step(PllState &s, float v, const PllCoef &c)
 {
@@ -85,6 +86,10 @@ __device__ __forceinline__ void pll_step(PllState &s, float v, const PllCoef &c)
         const float er = v > 0.0f ? -s.fr : (s.fr >= 0.0f ? 0.5f - s.fr : -0.5f - s.fr);
         eD = er * 6.28318530717958647692f;
     } else {
+        if (MATH == kFast) {
+            s.fbI = __builtin_amdgcn_cosf(s.fr);
+            s.fbQ = __builtin_amdgcn_sinf(s.fr);
+        }
         const float eI = v * s.fbI;
         const float eQ = v * (-1 * s.fbQ);
         eD = glibc235::atan2f_glibc(eQ, eI);
@@ -95,24 +100,53 @@ __device__ __forceinline__ void pll_step(PllState &s, float v, const PllCoef &c)
     s.off += 1;
     const float trigArg = static_cast<float>(c.w * static_cast<double>(s.off) + static_cast<double>(s.phase));
     if (MATH == kFast) {
-        const float sc = trigArg * c.ncoScale;
-        const double inv2pi = 0.15915494309189533577;
-        const double rev = static_cast<double>(trigArg) * inv2pi;
-        const float fr = static_cast<float>(rev - rint(rev));          // [-0.5, 0.5] revolutions
-        s.fr = fr;
-        s.fbI = __builtin_amdgcn_cosf(fr);
-        s.fbQ = __builtin_amdgcn_sinf(fr);
-        const double rev2 = static_cast<double>(sc + c.phaseAdjust) * inv2pi;
-        s.last = __builtin_amdgcn_cosf(static_cast<float>(rev2 - rint(rev2)));
+        const double rev = static_cast<double>(trigArg) * 0.15915494309189533577;
+        s.fr = static_cast<float>(rev - rint(rev));                    // [-0.5, 0.5] revolutions
     } else {
         glibc235::sincosf_glibc(trigArg, &s.fbQ, &s.fbI);
-        s.last = trigArg;
     }
+    s.last = trigArg;
 }
 
+// The fast step for an ordinary sample (|v| in (1e-20, 1e20): everything but exact zeros, denormal products and
+// non-finite values), without a branch: what the lanes of the parallel form run.  Identical arithmetic to
+// pll_step<kFast>'s closed-form path; written with selects so that the recurrence's critical path holds no
+// exec-mask manipulation (a divergent branch puts several scalar instructions and their vector<->scalar
+// hand-offs between two samples).
+__device__ __forceinline__ void pll_step_clean(PllState &s, float v, const PllCoef &c)
+{
+    const float half = s.fr >= 0.0f ? 0.5f : -0.5f;
+    const float turn = v > 0.0f ? 0.0f : half;
+    const float eD = (turn - s.fr) * 6.28318530717958647692f;
+    s.integ = s.integ + c.Ki * eD;
+    const float pe = c.Kp * eD;
+    s.phase = (s.phase + pe) + s.integ;
+    s.off += 1;
+    const float trigArg = static_cast<float>(c.w * static_cast<double>(s.off) + static_cast<double>(s.phase));
+    const double rev = static_cast<double>(trigArg) * 0.15915494309189533577;
+    s.fr = static_cast<float>(rev - rint(rev));
+    s.last = trigArg;
+}
+__device__ __forceinline__ bool pll_ordinary(float v) { return fabsf(v) > 1e-20f && fabsf(v) < 1e20f; }
+
+template <int MATH>
 __device__ __forceinline__ float nco_out(float trigArg, const PllCoef &c)
 {
-    return glibc235::cosf_glibc(trigArg * c.ncoScale + c.phaseAdjust);
+    const float a = trigArg * c.ncoScale + c.phaseAdjust;
+    if (MATH == kExact) return glibc235::cosf_glibc(a);
+    const double rev = static_cast<double>(a) * 0.15915494309189533577;
+    return __builtin_amdgcn_cosf(static_cast<float>(rev - rint(rev)));
+}
+
+// state[2], state[3] (feedbackI, feedbackQ) and state[4] (lastOut) from the raw end of a run
+template <int MATH>
+__device__ __forceinline__ void finish_state(PllState &s, const PllCoef &c)
+{
+    if (MATH == kFast) {
+        s.fbI = __builtin_amdgcn_cosf(s.fr);
+        s.fbQ = __builtin_amdgcn_sinf(s.fr);
+    }
+    s.last = nco_out<MATH>(s.last, c);
 }
 
 __device__ __forceinline__ PllState load_state(const float *st)
@@ -139,25 +173,35 @@ __global__ void pll_serial_kernel(const float *__restrict__ in, size_t n, float 
         const float v = vn;
         vn = in[k + 1 < n ? k + 1 : k];
         pll_step<MATH>(s, v, c);
-        out[k + 1] = s.last;                              // kExact: the raw trigArg, see nco_out_kernel
+        out[k + 1] = s.last;                              // the raw trigArg, see nco_out_kernel
     }
-    if (MATH == kExact) s.last = nco_out(s.last, c);
+    finish_state<MATH>(s, c);
     store_state(state, s);
 }
 
-// kExact, second pass: out[k] = cosf(trigArg[k]*ncoScale + phaseAdjust) for k = 1..n, in place
+// second pass, in parallel: out[k] = cosf(trigArg[k]*ncoScale + phaseAdjust) for k = 1..n, in place
+template <int MATH>
 __global__ void nco_out_kernel(float *__restrict__ out, size_t n, PllCoef c)
 {
     const size_t k = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (k < n) out[k + 1] = nco_out(out[k + 1], c);
+    if (k < n) out[k + 1] = nco_out<MATH>(out[k + 1], c);
 }
 
 // ---- parallel in time -------------------------------------------------------------------------
-// seg[s*16 + 0..5]  state at the END of segment s      (after sample a_s + L - 1)
+// seg[s*16 + 0..5]  state at the END of segment s      (after sample a_s + L - 1; fbI/fbQ/last finished)
 // seg[s*16 + 8..9]  (integ, phase) this lane had at the START of segment s (after its warm-up)
+//
+// Where a lane starts.  A locked loop is not just "near a constant": its phase carries the ripple of the
+// phase detector (a sawtooth per pilot half cycle, +-0.07 rad), and on a pilot that is on frequency that
+// ripple repeats with the pilot: every P = Fs / gcd(Fs, freq) samples (240 at 240 kHz: 19 pilot cycles)
+// the loop is in the same state again, up to its slow drift.  So a lane does not start "W samples early"
+// but at the last multiple of P (counted from the block start, where the true state is known) that is at
+// least W samples early, from the block's initial state plus the drift: its guess is then already within a
+// few grid steps of the true trajectory, and W only has to cover what the drift estimate misses (64
+// samples instead of the 768 it takes to forget a guess that ignores the ripple).  P = 0: no alignment.
 __global__ void pll_segments_kernel(const float *__restrict__ in, long n, float *__restrict__ out,
-                                    const float *__restrict__ state, PllCoef c, int L, int W, long nseg,
-                                    float *__restrict__ seg, const float *__restrict__ hdr)
+                                    const float *__restrict__ state, PllCoef c, int L, int W, int P, long nseg,
+                                    float *__restrict__ seg, float *hdr)
 {
     const long sg = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (sg >= nseg) return;
@@ -167,35 +211,80 @@ __global__ void pll_segments_kernel(const float *__restrict__ in, long n, float 
     PllState s = s0;
     long k = 0;
     if (a > W) {
-        // warm start W samples early; hdr[5..7] = {phase at the start of the previous call, its length, valid}
         k = a - W;
+        if (P > 0) k -= k % P;
+    }
+    if (k > 0) {
+        // hdr[5..7] = {phase at the start of the previous call, its length, valid}: the drift
         const float slope = hdr[7] != 0.0f ? (s0.phase - hdr[5]) / hdr[6] : 0.0f;
         s.phase = s0.phase + slope * static_cast<float>(k);
         s.off = s0.off + static_cast<float>(k);
         const float trigArg = static_cast<float>(c.w * static_cast<double>(s.off) + static_cast<double>(s.phase));
         const double rev = static_cast<double>(trigArg) * 0.15915494309189533577;
-        const float fr = static_cast<float>(rev - rint(rev));
-        s.fr = fr;
-        s.fbI = __builtin_amdgcn_cosf(fr);
-        s.fbQ = __builtin_amdgcn_sinf(fr);
+        s.fr = static_cast<float>(rev - rint(rev));
     }
-    // The recurrence is one long dependency chain; the samples it eats are not part of it.  They are
-    // fetched one step ahead so that a load's latency is never on the chain.
-    float vn = k < b ? in[k] : 0.0f;
-    for (; k < a; k++) {                                  // warm-up (or exact replay from the block start)
-        const float v = vn;
-        vn = in[k + 1 < b ? k + 1 : k];
-        pll_step<kFast>(s, v, c);
+    // The recurrence is one long dependency chain; the samples it eats are not part of it, and a load from
+    // L2 / HBM takes longer than several steps of the chain.  They are fetched as 16-byte groups, three groups
+    // (12 samples, ~1 us of chain) ahead.  k, a and L are multiples of 4 and `in` is 16-byte aligned with at
+    // least 12 readable floats behind in[n-1] (host contract), so every group is one aligned global_load_dwordx4.
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 *in4 = reinterpret_cast<const f4 *>(in);
+    const long last4 = (n + 3) / 4 + 1;                   // last group that is safe to read (floats up to n+10)
+    auto grp = [&](long g) { return in4[g < last4 ? g : last4]; };
+    long g = k / 4;
+    f4 q0 = grp(g), q1 = grp(g + 1), q2 = grp(g + 2);
+    for (; k < a; k += 4) {                               // warm-up (or exact replay from the block start)
+        const f4 cur = q0;
+        q0 = q1;
+        q1 = q2;
+        q2 = grp(++g + 2);
+        // one wave-uniform test per group: an odd sample anywhere in the wave sends the whole wave through the
+        // general step (same values for ordinary samples), so the common path has no divergent branch at all
+        if (__builtin_expect(__any(!(pll_ordinary(cur.x) && pll_ordinary(cur.y) && pll_ordinary(cur.z) && pll_ordinary(cur.w))), 0)) {
+            pll_step<kFast>(s, cur.x, c);
+            pll_step<kFast>(s, cur.y, c);
+            pll_step<kFast>(s, cur.z, c);
+            pll_step<kFast>(s, cur.w, c);
+        } else {
+            pll_step_clean(s, cur.x, c);
+            pll_step_clean(s, cur.y, c);
+            pll_step_clean(s, cur.z, c);
+            pll_step_clean(s, cur.w, c);
+        }
     }
     seg[sg * 16 + 8] = s.integ;
     seg[sg * 16 + 9] = s.phase;
-    if (sg == 0) out[0] = s0.last;
-    for (; k < b; k++) {
-        const float v = vn;
-        vn = in[k + 1 < b ? k + 1 : k];
-        pll_step<kFast>(s, v, c);
+    if (sg == 0) {
+        out[0] = s0.last;
+        hdr[1] = 0.0f;                                     // "some segment needs repair": set by pll_check_nco_kernel
+    }
+    for (; k + 4 <= b; k += 4) {
+        const f4 cur = q0;
+        q0 = q1;
+        q1 = q2;
+        q2 = grp(++g + 2);
+        float r0, r1, r2, r3;                              // raw trigArg: pll_check_nco_kernel applies the NCO
+        if (__builtin_expect(__any(!(pll_ordinary(cur.x) && pll_ordinary(cur.y) && pll_ordinary(cur.z) && pll_ordinary(cur.w))), 0)) {
+            pll_step<kFast>(s, cur.x, c); r0 = s.last;
+            pll_step<kFast>(s, cur.y, c); r1 = s.last;
+            pll_step<kFast>(s, cur.z, c); r2 = s.last;
+            pll_step<kFast>(s, cur.w, c); r3 = s.last;
+        } else {
+            pll_step_clean(s, cur.x, c); r0 = s.last;
+            pll_step_clean(s, cur.y, c); r1 = s.last;
+            pll_step_clean(s, cur.z, c); r2 = s.last;
+            pll_step_clean(s, cur.w, c); r3 = s.last;
+        }
+        out[k + 1] = r0;
+        out[k + 2] = r1;
+        out[k + 3] = r2;
+        out[k + 4] = r3;
+    }
+    for (int i = 0; k < b; k++, i++) {                    // the block's ragged end (last segment only)
+        pll_step<kFast>(s, q0[i], c);
         out[k + 1] = s.last;
     }
+    finish_state<kFast>(s, c);
     store_state(seg + sg * 16, s);
 }
 
@@ -218,23 +307,56 @@ __device__ __forceinline__ float pll_integ_tol(float base, const float *state, l
     return base + 2.0f * c.Ki * pll_trig_ulp(state, n, c);
 }
 
-// mark every segment whose start state differs from its predecessor's end state by more than the
-// merge tolerance; record the largest differences seen among the accepted ones (diagnostics)
-__global__ void pll_check_kernel(const float *__restrict__ seg, long nseg, unsigned long long *__restrict__ badmask,
-                                 float tol_phase_base, float tol_integ, unsigned *__restrict__ diag,
-                                 const float *__restrict__ state, long n, PllCoef c)
+// Judge and finish.  One workgroup per 256 segments: (1) mark every segment whose start state differs from its
+// predecessor's end state by more than the merge tolerance (the mask words are written whole: no memset, no
+// atomics) and record the largest differences among the accepted ones (diagnostics); (2) apply the NCO,
+// out[k+1] = cos(trigArg*ncoScale + phaseAdjust), in place to the workgroup's stretch of the output, leaving
+// out the segments just marked: pll_repair_kernel walks those again and writes finished values itself.
+constexpr int kCheckThreads = 256, kCheckSegs = 64;
+__global__ __launch_bounds__(kCheckThreads) void pll_check_nco_kernel(
+    const float *__restrict__ seg, long nseg, unsigned long long *__restrict__ badmask, float tol_phase_base, float tol_integ,
+    unsigned *__restrict__ diag, const float *__restrict__ state, long n, PllCoef c, int L, float *__restrict__ out)
 {
-    const long sg = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (sg < 1 || sg >= nseg) return;
-    const float tol_phase = pll_phase_tol(tol_phase_base, state, n, c);
-    tol_integ = pll_integ_tol(tol_integ, state, n, c);
-    const float di = fabsf(seg[sg * 16 + 8] - seg[(sg - 1) * 16 + 0]);
-    const float dp = fabsf(seg[sg * 16 + 9] - seg[(sg - 1) * 16 + 1]);
-    if (!(dp <= tol_phase && di <= tol_integ)) {
-        atomicOr(badmask + sg / 64, 1ull << (sg % 64));
-    } else {
-        atomicMax(diag + 3, __float_as_uint(dp));   // non-negative floats order like their bit patterns
-        atomicMax(diag + 4, __float_as_uint(di));
+    __shared__ unsigned long long word;
+    const long s0 = static_cast<long>(blockIdx.x) * kCheckSegs;
+    if (threadIdx.x < kCheckSegs) {                        // wave 0 judges the workgroup's 64 segments
+        const long sg = s0 + threadIdx.x;
+        const float tol_phase = pll_phase_tol(tol_phase_base, state, n, c);
+        tol_integ = pll_integ_tol(tol_integ, state, n, c);
+        bool bad = false;
+        float dp = 0.0f, di = 0.0f;
+        if (sg >= 1 && sg < nseg) {
+            di = fabsf(seg[sg * 16 + 8] - seg[(sg - 1) * 16 + 0]);
+            dp = fabsf(seg[sg * 16 + 9] - seg[(sg - 1) * 16 + 1]);
+            bad = !(dp <= tol_phase && di <= tol_integ);
+            if (bad) dp = di = 0.0f;
+        }
+        const unsigned long long m = __ballot(bad);
+        for (int o = 32; o; o >>= 1) {
+            dp = fmaxf(dp, __shfl_xor(dp, o, 64));
+            di = fmaxf(di, __shfl_xor(di, o, 64));
+        }
+        if (threadIdx.x == 0) {
+            word = m;
+            badmask[s0 / 64] = m;
+            if (m) reinterpret_cast<float *>(diag)[1] = 1.0f;          // every writer writes the same value
+            if (dp > 0.0f) atomicMax(diag + 3, __float_as_uint(dp));   // non-negative floats order like their bit patterns
+            if (di > 0.0f) atomicMax(diag + 4, __float_as_uint(di));
+        }
+    }
+    __syncthreads();
+    // the workgroup's stretch of the output in groups of 4 samples (L is a multiple of 4: a group lies in one segment)
+    const unsigned long long w = word;
+    const long k0 = s0 * L;
+    const long k1 = (s0 + kCheckSegs) * L < n ? (s0 + kCheckSegs) * L : n;
+    const float inv_lq = 4.0f / static_cast<float>(L);
+    for (long g = threadIdx.x; k0 + 4 * g < k1; g += kCheckThreads) {
+        const int ls = static_cast<int>((static_cast<float>(g) + 0.5f) * inv_lq);   // g / (L/4): exact for g < 2^20
+        if ((w >> ls) & 1ull) continue;
+        const long k = k0 + 4 * g;
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (k + e < k1) out[k + e + 1] = nco_out<kFast>(out[k + e + 1], c);
     }
 }
 
@@ -256,7 +378,8 @@ __global__ __launch_bounds__(kRepairThreads) void pll_repair_kernel(
     tol_integ = pll_integ_tol(tol_integ, state, n, c);
     auto is_bad = [&](long sg) { return (badmask[sg / 64] >> (sg % 64)) & 1ull; };
     unsigned repaired = 0;
-    for (;;) {
+    const bool nothing_to_do = hdr[1] == 0.0f;             // the common case: every segment merged
+    for (; !nothing_to_do;) {
         if (threadIdx.x == 0) any_todo = 0;
         __syncthreads();
         // this round's work is fixed before anything changes: bad segments with a valid predecessor
@@ -278,16 +401,25 @@ __global__ __launch_bounds__(kRepairThreads) void pll_repair_kernel(
                 const float v = vn;
                 vn = in[k + 1 < b ? k + 1 : k];
                 pll_step<kFast>(s, v, c);
-                out[k + 1] = s.last;
+                out[k + 1] = nco_out<kFast>(s.last, c);     // finished values: pll_check_nco_kernel left this segment out
             }
+            finish_state<kFast>(s, c);
             store_state(seg + sg * 16, s);
             repaired++;
             atomicAnd(badmask + sg / 64, ~(1ull << (sg % 64)));
             if (sg + 1 < nseg) {
                 const bool merged = fabsf(seg[(sg + 1) * 16 + 9] - s.phase) <= tol_phase &&
                                     fabsf(seg[(sg + 1) * 16 + 8] - s.integ) <= tol_integ;
-                if (merged) atomicAnd(badmask + (sg + 1) / 64, ~(1ull << ((sg + 1) % 64)));
-                else atomicOr(badmask + (sg + 1) / 64, 1ull << ((sg + 1) % 64));
+                const bool was_bad = is_bad(sg + 1);
+                if (merged) {
+                    atomicAnd(badmask + (sg + 1) / 64, ~(1ull << ((sg + 1) % 64)));
+                    if (was_bad) {   // its lane's trajectory stands after all, but its outputs are still raw trigArg
+                        const long a2 = (sg + 1) * L, b2 = a2 + L < n ? a2 + L : n;
+                        for (long k = a2; k < b2; k++) out[k + 1] = nco_out<kFast>(out[k + 1], c);
+                    }
+                } else {
+                    atomicOr(badmask + (sg + 1) / 64, 1ull << ((sg + 1) % 64));
+                }
             }
         }
         __threadfence();
@@ -336,17 +468,17 @@ int k_fm_pll(const float *d_in, size_t n, float *d_out, float *d_state, float fr
              float phaseAdjust, float normBandwidth, int fast, hipStream_t s)
 {
     const PllCoef c = make_coef(freq, Fs, ncoScale, phaseAdjust, normBandwidth);
+    const unsigned grid = static_cast<unsigned>((n + 255) / 256);
     if (fast) {
         hipLaunchKernelGGL(pll_serial_kernel<kFast>, dim3(1), dim3(64), 0, s, d_in, n, d_out, d_state, c);
         FMRX_LAUNCH_CHECK("pll_serial");
-        return FMRX_OK;
+        if (n) hipLaunchKernelGGL(nco_out_kernel<kFast>, dim3(grid), dim3(256), 0, s, d_out, n, c);
+    } else {
+        hipLaunchKernelGGL(pll_serial_kernel<kExact>, dim3(1), dim3(64), 0, s, d_in, n, d_out, d_state, c);
+        FMRX_LAUNCH_CHECK("pll_serial");
+        if (n) hipLaunchKernelGGL(nco_out_kernel<kExact>, dim3(grid), dim3(256), 0, s, d_out, n, c);
     }
-    hipLaunchKernelGGL(pll_serial_kernel<kExact>, dim3(1), dim3(64), 0, s, d_in, n, d_out, d_state, c);
-    FMRX_LAUNCH_CHECK("pll_serial");
-    if (n) {
-        hipLaunchKernelGGL(nco_out_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, d_out, n, c);
-        FMRX_LAUNCH_CHECK("nco_out");
-    }
+    FMRX_LAUNCH_CHECK("nco_out");
     return FMRX_OK;
 }
 
@@ -360,7 +492,7 @@ int k_libm_eval(int fn, const float *d_a, const float *d_b, size_t n, float *d_o
 
 size_t pll_parallel_scratch_floats(size_t n)
 {
-    const size_t nseg = n / kPllSegment + 2;
+    const size_t nseg = n / kPllSegmentMin + 2;
     return 8 + nseg * 16 + 2 * (nseg / 64 + 2);
 }
 
@@ -368,25 +500,35 @@ int k_fm_pll_parallel(const float *d_in, size_t n, float *d_out, float *d_state,
                       float phaseAdjust, float normBandwidth, float *d_scratch, const Options &o, hipStream_t s)
 {
     int L = kPllSegment, W = kPllWarmup;
-    if (o.pll_warmup >= 0 && o.pll_warmup <= 65536) W = o.pll_warmup;                 // tuning: warm-up samples per lane
-    if (o.pll_segment >= kPllSegment && o.pll_segment <= 65536) L = o.pll_segment;   // tuning: samples per lane (scratch is sized for >= kPllSegment)
+    if (o.pll_warmup >= 0 && o.pll_warmup <= 65536) W = o.pll_warmup / 4 * 4;                    // tuning: warm-up samples per lane
+    if (o.pll_segment >= kPllSegmentMin && o.pll_segment <= 65536) L = o.pll_segment / 4 * 4;   // tuning: samples per lane
+    if (reinterpret_cast<uintptr_t>(d_in) % 16)
+        return fail(FMRX_EINVAL, "fm_pll_parallel: input must be 16-byte aligned (the lanes fetch 16-byte groups)");
     if (n < static_cast<size_t>(4 * L))   // nothing to gain
         return k_fm_pll(d_in, n, d_out, d_state, freq, Fs, ncoScale, phaseAdjust, normBandwidth, 1, s);
     const PllCoef c = make_coef(freq, Fs, ncoScale, phaseAdjust, normBandwidth);
+    // the loop's state repeats every P samples on an on-frequency pilot: Fs / gcd(Fs, freq), when both are whole Hz
+    int P = 0;
+    if (o.pll_align != 0 && Fs == static_cast<float>(static_cast<long>(Fs)) && freq == static_cast<float>(static_cast<long>(freq)) && freq > 0) {
+        long x = static_cast<long>(Fs), y = static_cast<long>(freq);
+        while (y) { const long t = x % y; x = y; y = t; }
+        const long p = static_cast<long>(Fs) / x;
+        if (p > 0 && p <= 4096 && p % 4 == 0) P = static_cast<int>(p);
+    }
     const long nseg = static_cast<long>((n + L - 1) / L);
     // scratch: [2] repaired-segment counter (u32), [3],[4] largest accepted |dphase|,|dinteg| (diagnostics),
     // [5..7] previous call's start phase / length / valid; [8..] per-segment records, then the mismatch bitmask
     unsigned *n_repaired = reinterpret_cast<unsigned *>(d_scratch + 2);
     float *seg = d_scratch + 8;
     unsigned long long *badmask = reinterpret_cast<unsigned long long *>(seg + (nseg + 1) * 16);
-    FMRX_HIP(hipMemsetAsync(badmask, 0, (nseg / 64 + 1) * sizeof(unsigned long long), s));
     const unsigned grid = static_cast<unsigned>((nseg + 63) / 64);
-    hipLaunchKernelGGL(pll_segments_kernel, dim3(grid), dim3(64), 0, s, d_in, static_cast<long>(n), d_out, d_state, c, L, W,
+    hipLaunchKernelGGL(pll_segments_kernel, dim3(grid), dim3(64), 0, s, d_in, static_cast<long>(n), d_out, d_state, c, L, W, P,
                        nseg, seg, d_scratch);
     FMRX_LAUNCH_CHECK("pll_segments");
-    hipLaunchKernelGGL(pll_check_kernel, dim3(grid), dim3(64), 0, s, seg, nseg, badmask, kPllTolPhase, kPllTolInteg,
-                       reinterpret_cast<unsigned *>(d_scratch), d_state, static_cast<long>(n), c);
-    FMRX_LAUNCH_CHECK("pll_check");
+    hipLaunchKernelGGL(pll_check_nco_kernel, dim3(static_cast<unsigned>((nseg + kCheckSegs - 1) / kCheckSegs)), dim3(kCheckThreads), 0, s,
+                       seg, nseg, badmask, kPllTolPhase, kPllTolInteg, reinterpret_cast<unsigned *>(d_scratch), d_state,
+                       static_cast<long>(n), c, L, d_out);
+    FMRX_LAUNCH_CHECK("pll_check_nco");
     hipLaunchKernelGGL(pll_repair_kernel, dim3(1), dim3(kRepairThreads), 0, s, d_in, static_cast<long>(n), d_out, d_state, c, L, nseg, seg,
                        badmask, kPllTolPhase, kPllTolInteg, n_repaired, d_scratch);
     FMRX_LAUNCH_CHECK("pll_repair");

@@ -12,6 +12,7 @@
 //
 // Numerics: one FMA per tap, taps ascending in n as the reference does; differs
 // from its separate multiply/add by float32 rounding only (generic kernel = exact).
+#include "device_math.hpp"
 #include "fmrx_internal.hpp"
 
 namespace fmrx {
@@ -123,6 +124,80 @@ int launch(const BpfPairPlan &pl, const float *d_x, size_t n, float *d_st, float
     return FMRX_OK;
 }
 
+// ---- everything behind the PLL in one kernel (modes 0/1) --------------------------------------------
+// Replaces, fused: the mixer loop (src/project.cpp:246-248), the two audio convolveBlockFastFIR calls of
+// RF_STEREO -- mono branch on the all-passed discriminator output (:194, :219) and stereo branch on the
+// mixer output (:257) -- the L/R combine (:277-280) and the interleaved PCM writer (:292-302).
+// The two audio FIRs use the same taps on two streams, so they ride in the two halves of v_pk_fma_f32:
+//   acc(mono, st) += h[n] * (demod[D k - n - delay], mixer[D k - n]),  mixer[i] = stereo_filt[i] * nco[i] * 2
+// (the all-pass is the index offset `delay`).  A workgroup stages the window of NT*R audio outputs as (mono,
+// mixer) pairs in LDS -- the mixer products are formed while staging and never go to HBM -- and lane t
+// produces outputs t, t+NT, ...: neighbouring lanes are D pairs apart in LDS (conflict-free for D = 5, 2-way
+// for D = 6) and store neighbouring outputs.  Taps are wave-uniform scalar loads.  Samples before the block:
+// the discriminator history sits in front of its buffer (or at the tail of the previous block's), the mixer
+// history (state_stereofilt) is the tail the previous call left in mix_tail_in; this call leaves its own in
+// mix_tail_out (every workgroup that stages one of the block's last `hm` samples writes it: same values).
+template <int T, int D, int R, int NT>
+__global__ __launch_bounds__(NT) void stereo_out_kernel(const float *__restrict__ demod, const float *__restrict__ bpf,
+                                                         const float *__restrict__ nco, const float *__restrict__ mix_tail_in,
+                                                         float *__restrict__ mix_tail_out, int hm, long n_if, int delay,
+                                                         const float *__restrict__ h, float *__restrict__ mono_out,
+                                                         float *__restrict__ st_out, float *__restrict__ left, float *__restrict__ right,
+                                                         int16_t *__restrict__ pcm, int wrap, float *__restrict__ mixer_out, long n_out)
+{
+    constexpr int NOUT = NT * R;
+    constexpr int WL = D * (NOUT - 1) + T;
+    extern __shared__ f2 win[];
+    const int t = threadIdx.x;
+    const long a0 = static_cast<long>(blockIdx.x) * NOUT;
+    const long g0 = D * a0 - (T - 1);                      // IF index of window sample 0
+    // D-1 samples past the window are visited too: when the block ends exactly on a tile boundary nobody's window
+    // reaches the block's last D-1 samples, and they belong to the tail this call leaves behind
+    for (int j = t; j < WL + D - 1; j += NT) {
+        const long g = g0 + j;
+        float m = 0.0f, x = 0.0f;
+        if (g < n_if) {
+            m = demod[g - delay];                          // history in front of the buffer: negative indices are valid
+            if (g >= 0) {
+                x = (bpf[g] * nco[g]) * 2.0f;              // the reference's order: (stereo_filt * PLL) * 2
+                if (mixer_out) mixer_out[g] = x;
+                if (g >= n_if - hm) mix_tail_out[g - (n_if - hm)] = x;
+            } else {
+                x = mix_tail_in[hm + g];
+                if (n_if < hm && hm + g >= n_if) mix_tail_out[hm + g - n_if] = x;   // a block shorter than the history keeps what it must
+            }
+        }
+        if (j < WL) win[j] = (f2){m, x};
+    }
+    __syncthreads();
+    f2 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = (f2){0.0f, 0.0f};
+    const f2 *w0 = win + D * t + (T - 1);
+#pragma unroll 4
+    for (int n = 0; n < T; n++) {
+        const float hn = h[n];                             // wave-uniform: scalar load
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = __builtin_elementwise_fma(w0[D * NT * r - n], (f2){hn, hn}, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const long k = a0 + static_cast<long>(r) * NT + t;
+        if (k < n_out) {
+            const float mo = acc[r].x, st = acc[r].y;
+            const float l = st + mo, rr = mo - st;         // src/project.cpp:278-279
+            if (mono_out) mono_out[k] = mo;
+            if (st_out) st_out[k] = st;
+            if (left) left[k] = l;
+            if (right) right[k] = rr;
+            if (pcm) {
+                using s2 = short __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<s2 *>(pcm + 2 * k) = (s2){pcm_pack(l, wrap), pcm_pack(rr, wrap)};
+            }
+        }
+    }
+}
+
 // stereo tap counts in the reference: 13 (project.cpp:429), 151 (model), 101 (the report's final choice)
 #define FMRX_BPF_CASES(X) X(13) X(101) X(151)
 
@@ -167,6 +242,37 @@ int bpf_pair_launch(const BpfPairPlan &pl, const float *d_x, size_t n, float *d_
     }
     FMRX_TRY(k_fir_generic(d_x, n, pl.h_st.p, pl.taps, 1, d_st, stream));
     return k_fir_generic(d_x, n, pl.h_car.p, pl.taps, 1, d_car, stream);
+}
+
+// d_demod: block start, with >= taps-1+delay readable samples in front; d_nco[i] = PLL[i] (i < n_if);
+// d_mix_tail_in / _out: hm floats each (hm >= taps-1; index hm+g holds mixer sample g < 0)
+bool stereo_out_available(int taps, int decim)
+{
+    return (taps == 101 || taps == 13) && (decim == 5 || decim == 6);
+}
+
+int stereo_out_launch(const float *d_demod, const float *d_bpf, const float *d_nco, const float *d_mix_tail_in,
+                      float *d_mix_tail_out, int hm, size_t n_if, int delay, const float *d_h, int taps, int decim, float *d_mono,
+                      float *d_st, float *d_left, float *d_right, int16_t *d_pcm, int wrap, float *d_mixer, hipStream_t stream)
+{
+    const long n_out = static_cast<long>(n_if / decim);
+    if (n_out == 0) return FMRX_OK;
+    if (hm < taps - 1) return fail(FMRX_EINVAL, "stereo_out: mixer history shorter than taps-1");
+    constexpr int R = 2, NT = 256;
+    const unsigned grid = static_cast<unsigned>((n_out + NT * R - 1) / (NT * R));
+#define X(T_, D_)                                                                                                       \
+    if (taps == T_ && decim == D_) {                                                                                    \
+        constexpr size_t lds = (static_cast<size_t>(D_) * (NT * R - 1) + T_) * sizeof(f2);                              \
+        hipLaunchKernelGGL((stereo_out_kernel<T_, D_, R, NT>), dim3(grid), dim3(NT), lds, stream, d_demod, d_bpf, d_nco, \
+                           d_mix_tail_in, d_mix_tail_out, hm, static_cast<long>(n_if), delay, d_h, d_mono, d_st, d_left,  \
+                           d_right, d_pcm, wrap, d_mixer, n_out);                                                        \
+        hipError_t e = hipGetLastError();                                                                               \
+        if (e != hipSuccess) return fail(FMRX_EHIP, "launch stereo_out_kernel<%d,%d>: %s", T_, D_, hipGetErrorString(e)); \
+        return FMRX_OK;                                                                                                 \
+    }
+    X(101, 5) X(101, 6) X(13, 5) X(13, 6)
+#undef X
+    return fail(FMRX_EINVAL, "stereo_out_launch: no kernel for taps=%d decim=%d", taps, decim);
 }
 
 }  // namespace fmrx

@@ -42,6 +42,7 @@ struct fmrx_pipeline {
     bool prev_override = false;  // the next block takes IF[-1] from prev_iq (after set_state)
     bool if_valid = false;       // ifb holds the last block's IF samples
     bool demod_valid = true;     // the demod buffer holds the whole last block (not just its tail: fused mono kernel)
+    bool mixer_valid = false;    // the mixer output of the last block was stored (the fused stereo kernel keeps it on chip)
     bool pll_warm = false;       // the PLL has seen a block since reset / set_state (its state is a locked one)
     Options opt;                 // copied from the process defaults at creation; fmrx_pipeline_set_option
 
@@ -65,6 +66,10 @@ struct fmrx_pipeline {
     size_t demod_n_last = 0;     // its length; its history front is valid iff demod_front[demod_last]
     bool demod_front[2] = {true, true};
     DevBuf<float> carrier, bpf, pll, pll_state, pll_scratch, mixer, st_final, left, right;
+    // state_stereofilt: the mixer output's last Hm samples (index Hm+g holds sample g < 0), written by one call
+    // and read by the next: two buffers used alternately, mix_cur = the one the next call reads
+    DevBuf<float> mix_tail[2];
+    int mix_cur = 0;
     DevBuf<float> out_f32;
     DevBuf<int16_t> out_pcm;
 
@@ -102,16 +107,6 @@ size_t n_audio_of(const fmrx_pipeline *pl, size_t n_bytes)
     return n_if / pl->p.audio_decim;
 }
 
-// keep the last `keep` floats of [hist | block] in front for the next block
-int carry_history(fmrx_pipeline *pl, float *buf, int keep, size_t n_block, hipStream_t s)
-{
-    if (keep == 0) return FMRX_OK;
-    // source = buf[n_block .. n_block+keep) ; may overlap the destination when n_block < keep
-    FMRX_HIP(hipMemcpyAsync(pl->tmp_hist.p, buf + n_block, keep * sizeof(float), hipMemcpyDeviceToDevice, s));
-    FMRX_HIP(hipMemcpyAsync(buf, pl->tmp_hist.p, keep * sizeof(float), hipMemcpyDeviceToDevice, s));
-    return FMRX_OK;
-}
-
 int audio_stage(fmrx_pipeline *pl, const float *d_x, size_t n_in, int delay, float *d_y, hipStream_t s)
 {
     if (pl->resample) return resample_launch(pl->rs, d_x, n_in, delay, d_y, pl->opt, s, pl->force_generic);
@@ -134,13 +129,13 @@ int reset_state(fmrx_pipeline *pl)
     pl->demod_n_last = 0;
     pl->demod_front[0] = pl->demod_front[1] = true;
     if (pl->channels == 2) {
-        FMRX_HIP(hipMemsetAsync(pl->mixer.p, 0, pl->Hm * sizeof(float), s));
+        for (int i = 0; i < 2; i++) FMRX_HIP(hipMemsetAsync(pl->mix_tail[i].p, 0, pl->Hm * sizeof(float), s));
         const float init[6] = {0.0f, 0.0f, 1.0f, 0.0f, 1.0f, 0.0f};  // src/project.cpp:458
         FMRX_HIP(hipMemcpyAsync(pl->pll_state.p, init, sizeof(init), hipMemcpyHostToDevice, s));
         FMRX_HIP(hipMemsetAsync(pl->pll_scratch.p + 5, 0, 3 * sizeof(float), s));   // no phase-slope history yet
     }
     FMRX_HIP(hipStreamSynchronize(s));
-    pl->fe_cur = pl->prev_cur = 0;
+    pl->fe_cur = pl->prev_cur = pl->mix_cur = 0;
     pl->prev_override = false;
     pl->if_valid = false;
     pl->pll_warm = false;
@@ -241,6 +236,7 @@ int fmrx_pipeline_create(fmrx_pipeline **out, const fmrx_params *p, int channels
             FMRX_TRY(pl->pll_scratch.alloc(pll_parallel_scratch_floats(n_if)));
             FMRX_HIP(hipMemset(pl->pll_scratch.p, 0, 8 * sizeof(float)));
             FMRX_TRY(pl->mixer.alloc(pl->Hm + n_if + 16));
+            for (int i = 0; i < 2; i++) FMRX_TRY(pl->mix_tail[i].alloc(pl->Hm + 4));
             FMRX_TRY(pl->st_final.alloc(n_au));
             FMRX_TRY(pl->left.alloc(n_au));
             FMRX_TRY(pl->right.alloc(n_au));
@@ -399,9 +395,14 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
     if (!pl->force_generic && mfma && fe_mfma_available(pl->fe, d_iq, n, hist)) {
         // matrix-core kernel: int8 MFMA FIR + discriminator, HBM-bound (kernels_fe_mfma.hip)
         hist_done = n_bytes >= static_cast<size_t>(hb);
+        // everything but mono modes 0/1 reads the discriminator history at negative indices of this block's buffer:
+        // the kernel copies it there itself (it is the tail of the previous block's buffer)
+        const bool want_front = !(pl->channels == 1 && !pl->resample) && n_if >= static_cast<size_t>(pl->Hd);
         FMRX_TRY(fe_mfma_launch(pl->fe, d_iq, n, hist, pl->prev_override ? prev : nullptr, demod,
                                 pl->keep_if ? pl->ifb.p : nullptr, prev_next,
-                                hist_done ? hist_next : nullptr, pl->opt, s));
+                                hist_done ? hist_next : nullptr, pl->opt, s, want_front ? hist_end - pl->Hd : nullptr,
+                                want_front ? dbuf : nullptr, pl->Hd));
+        if (want_front) pl->demod_front[cur] = true;
         pl->if_valid = pl->keep_if;
     } else if (!pl->force_generic && fe_fused_available(pl->fe, d_iq, n)) {
         // one kernel; the IF stream is written only when somebody asked to look at it, and the kernel
@@ -454,8 +455,11 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
         if (prof) FMRX_HIP(hipEventRecord(ev[2], s));
     } else {
         // ---- RF_STEREO: project.cpp:194-280 ----
+        const bool fused_out = !pl->resample && !pl->force_generic && stereo_out_available(p.audio_taps, p.audio_decim);
         float *mixer = pl->mixer.p + pl->Hm;
-        FMRX_TRY(audio_stage(pl, demod, n_if, pl->delay, pl->mono.p, s));  // all-pass = index offset
+        if (!fused_out) {
+            FMRX_TRY(audio_stage(pl, demod, n_if, pl->delay, pl->mono.p, s));  // all-pass = index offset
+        }
         if (prof) FMRX_HIP(hipEventRecord(ev[2], s));
         FMRX_TRY(bpf_pair_launch(pl->bpf_plan, demod, n_if, pl->bpf.p, pl->carrier.p, s, pl->force_generic));
         if (pl->force_generic || pl->opt.pll_mode != 0) {
@@ -478,10 +482,31 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
                                            static_cast<float>(p.if_Fs), 2.0f, 0.0f, 0.01f, pl->pll_scratch.p, pl->opt, s));
             pl->pll_warm = true;
         }
+        const float *tail_in = pl->mix_tail[pl->mix_cur].p;
+        float *tail_out = pl->mix_tail[pl->mix_cur ^ 1].p;
+        if (fused_out) {
+            // mixer, both audio FIRs, L/R combine and PCM in one kernel, straight into the caller's buffers
+            FMRX_TRY(stereo_out_launch(demod, pl->bpf.p, pl->pll.p, tail_in, tail_out, pl->Hm, n_if, pl->delay, pl->audio.h.p,
+                                       p.audio_taps, p.audio_decim, pl->mono.p, pl->st_final.p,
+                                       d_audio_f32 ? d_audio_f32 : (d_pcm16 ? nullptr : pl->left.p),
+                                       d_audio_f32 ? d_audio_f32 + n_au : (d_pcm16 ? nullptr : pl->right.p), d_pcm16,
+                                       pcm_policy, pl->keep_if ? mixer : nullptr, s));
+            pl->mixer_valid = pl->keep_if;
+            pl->mix_cur ^= 1;
+            if (prof) {
+                FMRX_HIP(hipEventRecord(ev[3], s));
+                pl->calls++;
+            }
+            return FMRX_OK;
+        }
+        FMRX_HIP(hipMemcpyAsync(pl->mixer.p, tail_in, pl->Hm * sizeof(float), hipMemcpyDeviceToDevice, s));
         FMRX_TRY(k_mix(pl->bpf.p, pl->pll.p, n_if, mixer, s));
         FMRX_TRY(audio_stage(pl, mixer, n_if, 0, pl->st_final.p, s));
         FMRX_TRY(k_combine(pl->st_final.p, pl->mono.p, n_au, pl->left.p, pl->right.p, s));
-        FMRX_TRY(carry_history(pl, pl->mixer.p, pl->Hm, n_if, s));
+        // the mixer output's last Hm samples (of [history | block]) are the next block's state_stereofilt
+        FMRX_HIP(hipMemcpyAsync(tail_out, pl->mixer.p + n_if, pl->Hm * sizeof(float), hipMemcpyDeviceToDevice, s));
+        pl->mix_cur ^= 1;
+        pl->mixer_valid = true;
         out_l = pl->left.p;
         out_r = pl->right.p;
     }
@@ -545,7 +570,12 @@ int fmrx_pipeline_read_tap(fmrx_pipeline *pl, int which, float *out, size_t *n)
     case FMRX_TAP_CARRIER: if (st) { src = pl->carrier.p; cnt = n_if; } break;
     case FMRX_TAP_STEREO_BPF: if (st) { src = pl->bpf.p; cnt = n_if; } break;
     case FMRX_TAP_PLL: if (st) { src = pl->pll.p; cnt = n_if + 1; } break;
-    case FMRX_TAP_MIXER: if (st) { src = pl->mixer.p + pl->Hm; cnt = n_if; } break;
+    case FMRX_TAP_MIXER:
+        if (st) { src = pl->mixer.p + pl->Hm; cnt = n_if; }
+        if (st && out && cnt && !pl->mixer_valid)
+            return fail(FMRX_EINVAL, "read_tap: the fused stereo kernel keeps the mixer output on chip; call "
+                                     "fmrx_pipeline_set_keep_intermediates(pl, 1) before processing");
+        break;
     case FMRX_TAP_STEREO_FINAL: if (st) { src = pl->st_final.p; cnt = n_au; } break;
     default: return fail(FMRX_EINVAL, "read_tap: unknown tap %d", which);
     }
@@ -605,7 +635,7 @@ int fmrx_pipeline_get_state(fmrx_pipeline *pl, float *state, size_t n)
     if (pl->channels == 2) {
         std::memcpy(o, dend - (pl->St - 1), (pl->St - 1) * sizeof(float)); o += pl->St - 1;  // state_stereo
         std::memcpy(o, dend - (pl->St - 1), (pl->St - 1) * sizeof(float)); o += pl->St - 1;  // state_carrier
-        FMRX_HIP(hipMemcpy(o, pl->mixer.p + (pl->Hm - pl->Ha), pl->Ha * sizeof(float), hipMemcpyDeviceToHost)); o += pl->Ha;  // state_stereofilt
+        FMRX_HIP(hipMemcpy(o, pl->mix_tail[pl->mix_cur].p + (pl->Hm - pl->Ha), pl->Ha * sizeof(float), hipMemcpyDeviceToHost)); o += pl->Ha;  // state_stereofilt
         std::memcpy(o, dend - pl->delay, pl->delay * sizeof(float)); o += pl->delay;        // state_allpass
         FMRX_HIP(hipMemcpy(o, pl->pll_state.p, 6 * sizeof(float), hipMemcpyDeviceToHost)); o += 6;
     }
@@ -644,8 +674,8 @@ int fmrx_pipeline_set_state(fmrx_pipeline *pl, const float *state, size_t n)
         std::memcpy(dend - pl->delay, s_ap, pl->delay * sizeof(float));
         std::memcpy(dend - (pl->St - 1), s_st, (pl->St - 1) * sizeof(float));
         (void)s_car;  // identical to state_stereo by construction (same input stream)
-        FMRX_HIP(hipMemset(pl->mixer.p, 0, pl->Hm * sizeof(float)));
-        FMRX_HIP(hipMemcpy(pl->mixer.p + (pl->Hm - pl->Ha), s_sf, pl->Ha * sizeof(float), hipMemcpyHostToDevice));
+        FMRX_HIP(hipMemset(pl->mix_tail[pl->mix_cur].p, 0, pl->Hm * sizeof(float)));
+        FMRX_HIP(hipMemcpy(pl->mix_tail[pl->mix_cur].p + (pl->Hm - pl->Ha), s_sf, pl->Ha * sizeof(float), hipMemcpyHostToDevice));
         FMRX_HIP(hipMemcpy(pl->pll_state.p, o, 6 * sizeof(float), hipMemcpyHostToDevice));
         o += 6;
     } else {

@@ -39,7 +39,8 @@ def main():
     t_end = (np.arange(len(Lo) // win) + 1) * 0.1
     rows = {}
     for name, cfg in (("fast/parallel", {}), ("fast/serial", {"pll_mode": 1}), ("fast/glibc", {"pll_mode": 2}),
-                      ("valu/parallel", {"fe_variant": 1}), ("bit-exact", {"generic": 1})):
+                      ("par W512 L64", {"pll_warmup": 512, "pll_segment": 64}), ("par W384 L64", {"pll_warmup": 384, "pll_segment": 64}),
+                      ("par W256 L64", {"pll_warmup": 256, "pll_segment": 64}), ("bit-exact", {"generic": 1})):
         pl = fmrx.Pipeline(0, 2, max_block_bytes=bb)
         for k, v in cfg.items():
             if k == "generic":
