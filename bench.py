@@ -329,6 +329,30 @@ def side_legs(torch, fmrx, synth, args, pl, step, d_iq, n_bytes, stream) -> dict
     legs["small_block"] = {"what": "mode 0 mono, one 51,200-sample reference block per call (what a live 2.4 MS/s channel delivers)",
                            "us_per_block": round(ms * 1e3, 2), "x_real_time": round(51200 / 2.4e6 / (ms * 1e-3), 1)}
     q.close()
+    legs["small_block"]["fused_kernel_us_per_block"] = None
+    q = fmrx.Pipeline(0, 1, device=torch.cuda.current_device())
+    q.set_option("fused_min_audio", 0)
+    ms = event_ms(torch, lambda: q.process_dev(d_iq.data_ptr(), 102400, None, d_pcm.data_ptr(), wrap=True, stream=stream), 200, warm=20)
+    legs["small_block"]["fused_kernel_us_per_block"] = round(ms * 1e3, 2)
+    q.close()
+    # (5b) the same regime done properly: the current reference-size block of N live channels in ONE launch
+    #      (fmrx_channels_*; every channel's state is its last bytes, csrc/channels.hip)
+    nch = 4096
+    chs = fmrx.Channels(0, nch, device=torch.cuda.current_device())
+    blk = torch.from_numpy(synth.synth_fm_u8(51200, 2.4e6, seed=0x3D74 + 77)).cuda()
+    src = blk.repeat(nch)                                   # every channel gets (a copy of) the block
+    chs.load_dev(src.data_ptr(), stream)
+    d_pcm_all = torch.empty(nch * chs.n_audio, dtype=torch.int16, device="cuda")
+    ms = event_ms(torch, lambda: chs.process_dev(None, d_pcm_all.data_ptr(), wrap=True, stream=stream), 20, warm=5)
+    legs["channels_batch"] = {
+        "what": f"{nch} independent mode-0 mono channels, one 51,200-sample reference block each, per call (fmrx_channels_process_dev: one fused "
+                "launch over all slots + one finishing kernel; inputs resident in HBM)",
+        "ms_per_call": round(ms, 4), "value": round(nch * 51200 / (ms * 1e-3) / 1e6, 1), "unit": "MS/s",
+        "us_per_channel_block": round(ms * 1e3 / nch, 4),
+        "channels_at_real_time": int(nch * (51200 / 2.4e6) / (ms * 1e-3)),
+        "note": "channels_at_real_time = how many 2.4 MS/s channels one GPU keeps up with when their blocks are already in HBM (PCIe would cap "
+                "a live feed at ~13,000 channels per GPU: 64 GB/s / 4.8 MB/s)"}
+    del chs, src, d_pcm_all
     # (6) what this box's memory system gives a pure streaming read, by the access methods the kernels use
     reads = {}
     for method, label in ((0, "global_load_dwordx4 non-temporal to registers"), (1, "LDS-DMA ring (the matrix-core kernels' method)")):

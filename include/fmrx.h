@@ -279,6 +279,32 @@ FMRX_API int fmrx_pipeline_set_force_generic(fmrx_pipeline *pl, int on);
 FMRX_API int fmrx_pipeline_set_option(fmrx_pipeline *pl, const char *name, long value);
 
 /* ------------------------------------------------------------------ */
+/* many mono channels per device call                                   */
+/* ------------------------------------------------------------------ */
+/* The reference runs one receiver per process (one PARAMS / STATES set, src/project.cpp:460-468); a bank of N
+ * receivers is N processes.  fmrx_channels processes the current block of N independent mono channels (modes 0
+ * and 1) in ONE kernel launch: what a live multi-channel receiver needs, where one 51 200-sample block per
+ * channel and launch would leave the chip idle.  A channel's whole carried state is its last ~1 200 input
+ * samples, kept as raw bytes in front of its block (csrc/channels.hip); results equal fmrx_pipeline's for the
+ * same stream (audio to within float32 summation order, <= 2e-6; PCM +-1 LSB).
+ *   block_bytes: bytes per channel and call (a multiple of 16 and of 2*rf_decim*audio_decim; the reference's
+ *   p->block_bytes qualifies).  Input: either host memory, channel-major [n_channels][block_bytes]
+ *   (fmrx_channels_process), or written by the caller straight into device memory: channel c's block goes to
+ *   d_first_block + c*pitch_bytes (fmrx_channels_input_layout), then fmrx_channels_process_dev.
+ *   Output: [n_channels][n_audio] float and/or s16, n_audio = fmrx_channels_n_audio(). */
+typedef struct fmrx_channels fmrx_channels;
+FMRX_API int fmrx_channels_create(fmrx_channels **out, const fmrx_params *p, int n_channels, size_t block_bytes, int device);
+FMRX_API int fmrx_channels_destroy(fmrx_channels *c);
+FMRX_API size_t fmrx_channels_n_audio(const fmrx_channels *c);
+FMRX_API int fmrx_channels_input_layout(const fmrx_channels *c, uint8_t **d_first_block, size_t *pitch_bytes);
+/* back to the start-of-stream state: one channel, or all of them (channel < 0) */
+FMRX_API int fmrx_channels_reset(fmrx_channels *c, int channel);
+/* device-resident channel-major blocks [n_channels][block_bytes] -> the slots (one strided device copy, async on `stream`) */
+FMRX_API int fmrx_channels_load_dev(fmrx_channels *c, const uint8_t *d_iq, void *stream);
+FMRX_API int fmrx_channels_process(fmrx_channels *c, const uint8_t *iq, float *audio_f32, int16_t *pcm16, int pcm_policy);
+FMRX_API int fmrx_channels_process_dev(fmrx_channels *c, float *d_audio_f32, int16_t *d_pcm16, int pcm_policy, void *stream);
+
+/* ------------------------------------------------------------------ */
 /* fused front end (the hot kernel) as a stage of its own               */
 /* ------------------------------------------------------------------ */
 /* Fused: u8 I/Q -> (u8-128)/128 -> rf low-pass FIR -> decimate, I and Q

@@ -114,6 +114,14 @@ _sig("fmrx_pipeline_set_force_generic", [_vp, _int])
 _sig("fmrx_pipeline_set_keep_intermediates", [_vp, _int])
 _sig("fmrx_pipeline_set_option", [_vp, C.c_char_p, C.c_long])
 _sig("fmrx_pipeline_pll_diagnostics", [_vp, C.POINTER(_uint), C.POINTER(_flt), C.POINTER(_flt)])
+_sig("fmrx_channels_create", [C.POINTER(_vp), C.POINTER(Params), _int, _sz, _int])
+_sig("fmrx_channels_destroy", [_vp])
+_sig("fmrx_channels_n_audio", [_vp], _sz)
+_sig("fmrx_channels_input_layout", [_vp, C.POINTER(_vp), C.POINTER(_sz)])
+_sig("fmrx_channels_reset", [_vp, _int])
+_sig("fmrx_channels_load_dev", [_vp, _vp, _vp])
+_sig("fmrx_channels_process", [_vp, _u8p, _vp, _vp, _int])
+_sig("fmrx_channels_process_dev", [_vp, _vp, _vp, _int, _vp])
 _sig("fmrx_fe_fir_decim_u8", [_u8p, _sz, _f32p, _sz, _uint, _vp, _vp, _vp, _int])
 _sig("fmrx_fe_plan_create", [C.POINTER(_vp), _f32p, _sz, _uint])
 _sig("fmrx_fe_plan_destroy", [_vp])
@@ -438,6 +446,50 @@ class Pipeline:
         t, n = np.zeros(4, np.float32), _int(0)
         _check(lib.fmrx_pipeline_timing_sum(self._h, t, C.byref(n), max_calls))
         return dict(front_end_ms=float(t[0]), audio_ms=float(t[1]), rest_ms=float(t[2]), total_ms=float(t[3])), n.value
+
+
+class Channels:
+    """N independent mono channels (modes 0/1), the current block of all of them in one device call (fmrx_channels_*)."""
+
+    def __init__(self, mode=0, n_channels=1, rf_taps=101, base_audio_taps=101, block_bytes=None, device=0, params: Params | None = None):
+        self.params = params if params is not None else modeParams(mode, rf_taps, base_audio_taps, 101)
+        self.n_channels = int(n_channels)
+        self.block_bytes = int(block_bytes or self.params.block_bytes)
+        self._h = _vp()
+        _check(lib.fmrx_channels_create(C.byref(self._h), C.byref(self.params), self.n_channels, self.block_bytes, device))
+        self.n_audio = lib.fmrx_channels_n_audio(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None) and lib is not None:
+            lib.fmrx_channels_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def reset(self, channel=-1):
+        _check(lib.fmrx_channels_reset(self._h, channel))
+
+    def input_layout(self):
+        """(device address of channel 0's block, pitch in bytes between channels)."""
+        ptr, pitch = _vp(), _sz(0)
+        _check(lib.fmrx_channels_input_layout(self._h, C.byref(ptr), C.byref(pitch)))
+        return ptr.value, pitch.value
+
+    def process(self, iq_u8, want_pcm=True, wrap=True):
+        """iq_u8: [n_channels, block_bytes] uint8 (host) -> dict(audio=[n_channels, n_audio] f32, pcm16=... s16)."""
+        iq = _u8(iq_u8).reshape(self.n_channels, self.block_bytes)
+        f = np.zeros((self.n_channels, self.n_audio), np.float32)
+        s = np.zeros((self.n_channels, self.n_audio), np.int16) if want_pcm else None
+        _check(lib.fmrx_channels_process(self._h, iq.reshape(-1), f.ctypes.data, s.ctypes.data if want_pcm else None,
+                                         PCM_WRAP if wrap else PCM_SATURATE))
+        return {"audio": f, "pcm16": s}
+
+    def load_dev(self, d_iq_ptr, stream=None):
+        """Device-resident [n_channels, block_bytes] blocks -> the channels' slots (async on `stream`)."""
+        _check(lib.fmrx_channels_load_dev(self._h, d_iq_ptr, stream))
+
+    def process_dev(self, d_audio_ptr=None, d_pcm_ptr=None, wrap=True, stream=None):
+        _check(lib.fmrx_channels_process_dev(self._h, d_audio_ptr, d_pcm_ptr, PCM_WRAP if wrap else PCM_SATURATE, stream))
 
 
 class FrontEndPlan:

@@ -557,8 +557,8 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
             if (t >= t0 && static_cast<long>(t + 1) * C::TILE_OUT > n_out - tail_keep &&   // wave-uniform: last tiles only
                 o + 2 > n_out - tail_keep && o < n_out) {
                 // state_mono and prev_i/prev_q for the next block (the discriminator's last samples)
-                if (o >= n_out - tail_keep) demod_tail[o] = d0;
-                if (o + 1 < n_out) demod_tail[o + 1] = d1;
+                if (demod_tail && o >= n_out - tail_keep) demod_tail[o] = d0;
+                if (demod_tail && o + 1 < n_out) demod_tail[o + 1] = d1;
                 if (prev_out && o + 2 == n_out) *prev_out = make_float2(v[2], v[3]);
                 if (prev_out && o + 1 == n_out) *prev_out = make_float2(v[0], v[1]);
             }
@@ -734,7 +734,7 @@ int mono_fused_launch(const FePlan &fe, const AudioPlan &au, const uint8_t *d_iq
                       const float *d_prev, const float *d_dhist_end, float *d_demod_tail, int tail_keep, float *d_prev_out,
                       float *d_audio, int16_t *d_pcm, int wrap, uint8_t *d_hist_next, const Options &o, hipStream_t stream)
 {
-    if (!d_prev || !d_dhist_end || !d_demod_tail) return fail(FMRX_EINVAL, "mono_fused_launch: null argument");
+    if (!d_prev || !d_dhist_end) return fail(FMRX_EINVAL, "mono_fused_launch: null argument");
 #ifdef FMRX_TUNING
     if (const int v = o.fused_tune) {   // ablation variants, (101,10,101,5) only
 #define Y(ID_, P_, DR_, G_, K_)                                                                                            \
