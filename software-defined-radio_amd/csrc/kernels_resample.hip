@@ -70,7 +70,8 @@ __global__ __launch_bounds__(kNT) void resample_poly_kernel(const float *__restr
     y[k] = acc + g;
 }
 
-constexpr int kLT = 1024;   // threads = outputs per tile of the LDS-table kernel
+constexpr int kLT = 1024;    // threads of the LDS-table kernel
+constexpr int kLR = 1;       // outputs per thread and tile (2 was measured: the kernel is bound by LDS bandwidth and bank conflicts, not by the chain latency: no faster)
 constexpr int kRowPad = 4;   // floats: rows then start on all 16 bank groups, not 8
 
 __global__ __launch_bounds__(kLT) void resample_lds_kernel(const float *__restrict__ x, long n_in, long n_out,
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(kLT) void resample_lds_kernel(const float *__restri
     float *xs = lds + upsamp * WP;          // [span]
     const int t = threadIdx.x;
     const int w4 = W / 4;
+    constexpr int TILE = kLT * kLR;         // outputs per tile
     for (int i = t; i < upsamp * w4; i += kLT) {
         const int row = i / w4, c = i - row * w4;
         f4 v = (f4){0.0f, 0.0f, 0.0f, 0.0f};
@@ -92,10 +94,10 @@ __global__ __launch_bounds__(kLT) void resample_lds_kernel(const float *__restri
     }
     // the next tile's inputs are fetched into registers while this tile is multiplied (one workgroup
     // per CU: nothing else would hide the fetch)
-    constexpr int kNL = 8;                              // >= span / kLT (host checks)
+    constexpr int kNL = 16;                             // >= span / kLT (host checks)
     float xn[kNL];
     auto fetch = [&](long tile) {
-        const long lo = (tile * kLT * decim) / upsamp - (J - 1);   // oldest input any output of the tile touches
+        const long lo = (tile * TILE * decim) / upsamp - (J - 1);   // oldest input any output of the tile touches
 #pragma unroll
         for (int q = 0; q < kNL; q++) {
             const int i = t + q * kLT;
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(kLT) void resample_lds_kernel(const float *__restri
     };
     if (static_cast<long>(blockIdx.x) < n_tiles) fetch(blockIdx.x);
     for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const long k0 = tile * kLT;
+        const long k0 = tile * TILE;
         const long lo = (k0 * decim) / upsamp - (J - 1);
         __syncthreads();                                // the previous tile's reads of xs (and the table fill)
 #pragma unroll
@@ -113,37 +115,59 @@ __global__ __launch_bounds__(kLT) void resample_lds_kernel(const float *__restri
             if (t + q * kLT < span) xs[t + q * kLT] = xn[q];
         __syncthreads();
         if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
-        const long k = k0 + t;
-        if (k >= n_out) continue;
-        const long m = k * decim;
-        const int ph = static_cast<int>(m % upsamp);
-        const int b = static_cast<int>(m / upsamp - lo) - j0;   // index in xs of the sample tap j0 meets
-        const f4 *row = reinterpret_cast<const f4 *>(tab + ph * WP);
-        float acc = first ? 0.0f : y[k];
+        // kLR outputs per thread, kLT apart (coalesced stores): every output keeps the reference's own chain -- products
+        // and sums separately rounded, j ascending -- so the result is bit-exact; the chains of a thread are independent
+        // and fill each other's latency
+        const f4 *row[kLR];
+        const float *xp[kLR];
+        float acc[kLR];
+        long kk[kLR];
+#pragma unroll
+        for (int r = 0; r < kLR; r++) {
+            const long k = k0 + t + static_cast<long>(r) * kLT;
+            kk[r] = k < n_out ? k : -1;
+            const long m = (k < n_out ? k : k0) * decim;
+            const int ph = static_cast<int>(m % upsamp);
+            const int b = static_cast<int>(m / upsamp - lo) - j0;   // index in xs of the sample tap j0 meets
+            row[r] = reinterpret_cast<const f4 *>(tab + ph * WP);
+            xp[r] = xs + b;
+            acc[r] = (first || kk[r] < 0) ? 0.0f : y[kk[r]];
+        }
         const int nfull = (J - j0) / 4 < w4 ? (J - j0) / 4 : w4;   // groups of 4 taps that exist entirely
-        const float *xp = xs + b;
         for (int j4 = 0; j4 < nfull; j4++) {
-            const f4 h = row[j4];
+            f4 h[kLR];
+#pragma unroll
+            for (int r = 0; r < kLR; r++) h[r] = row[r][j4];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const float prod = h[e] * xp[-(4 * j4 + e)];
-                acc = acc + prod;
+#pragma unroll
+                for (int r = 0; r < kLR; r++) {
+                    const float prod = h[r][e] * xp[r][-(4 * j4 + e)];
+                    acc[r] = acc[r] + prod;
+                }
             }
         }
         if (nfull < w4) {                                          // the group the filter ends in
-            const f4 h = row[nfull];
 #pragma unroll
-            for (int e = 0; e < 4; e++)
-                if (j0 + 4 * nfull + e < J) {
-                    const float prod = h[e] * xp[-(4 * nfull + e)];
-                    acc = acc + prod;
-                }
+            for (int r = 0; r < kLR; r++) {
+                const f4 h = row[r][nfull];
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (j0 + 4 * nfull + e < J) {
+                        const float prod = h[e] * xp[r][-(4 * nfull + e)];
+                        acc[r] = acc[r] + prod;
+                    }
+            }
         }
-        if (last) {
-            const float g = acc * static_cast<float>(upsamp);
-            y[k] = acc + g;
-        } else {
-            y[k] = acc;
+#pragma unroll
+        for (int r = 0; r < kLR; r++) {
+            if (kk[r] < 0) continue;
+            if (last) {
+                const float g = acc[r] * static_cast<float>(upsamp);
+                y[kk[r]] = acc[r] + g;
+            } else {
+                y[kk[r]] = acc[r];
+            }
         }
     }
 }
@@ -168,12 +192,12 @@ int resample_plan_init(ResamplePlan &pl, const float *h, int taps, int decim, in
     pl.span = static_cast<int>((static_cast<long>(kNT) * decim + upsamp - 1) / upsamp) + pl.J + 1;
     pl.fast = pl.span * sizeof(float) <= 60 * 1024;
     // LDS-table kernel: as few passes as make (all phases x W taps) + one tile's inputs fit 144 KB of LDS
-    pl.span_l = static_cast<int>((static_cast<long>(kLT) * decim + upsamp - 1) / upsamp) + pl.J + 1;
+    pl.span_l = static_cast<int>((static_cast<long>(kLT) * kLR * decim + upsamp - 1) / upsamp) + pl.J + 1;
     pl.npass = 0;
     for (int np = 1; np <= 4; np++) {
         const int W = (pl.JP / 4 + np - 1) / np * 4;
-        if (pl.span_l <= 8 * kLT &&   // the kernel prefetches a tile's inputs in 8 registers per thread
-            (static_cast<long>(upsamp) * (W + kRowPad) + pl.span_l) * sizeof(float) <= 144 * 1024) {
+        if (pl.span_l <= 16 * kLT &&   // the kernel prefetches a tile's inputs in 16 registers per thread
+            (static_cast<long>(upsamp) * (W + kRowPad) + pl.span_l) * sizeof(float) <= 160 * 1024) {
             pl.npass = np;
             pl.W = W;
             break;
@@ -198,11 +222,11 @@ int resample_launch(const ResamplePlan &pl, const float *d_x, size_t n_in, int d
             FMRX_HIP(hipGetDevice(&dev));
             if (dev < 0 || dev >= 64 || !raised[dev]) {
                 FMRX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_lds_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 if (dev >= 0 && dev < 64) raised[dev] = true;
             }
         }
-        const long n_tiles = static_cast<long>((n_out + kLT - 1) / kLT);
+        const long n_tiles = static_cast<long>((n_out + kLT * kLR - 1) / (kLT * kLR));
         const unsigned grid = static_cast<unsigned>(n_tiles < 256 ? n_tiles : 256);
         for (int pass = 0; pass < pl.npass; pass++) {
             hipLaunchKernelGGL(resample_lds_kernel, dim3(grid), dim3(kLT), lds_bytes, stream, d_x - delay,
