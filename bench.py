@@ -353,6 +353,23 @@ def side_legs(torch, fmrx, synth, args, pl, step, d_iq, n_bytes, stream) -> dict
         "note": "channels_at_real_time = how many 2.4 MS/s channels one GPU keeps up with when their blocks are already in HBM (PCIe would cap "
                 "a live feed at ~13,000 channels per GPU: 64 GB/s / 4.8 MB/s)"}
     del chs, src, d_pcm_all
+    # (5c) the RDS path (float64 chain on the discriminator output + host bit recovery), the model's block size
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from rds_signal import rds_demod_signal
+        xr, _ = rds_demod_signal(8 * 9600, 240e3, seed=3, chip_offset=66.0)
+        rds = fmrx.Rds(0)
+        rds.process(xr[:9600])
+        t0 = time.perf_counter()
+        for b in range(1, 8):
+            rds.process(xr[b * 9600:(b + 1) * 9600])
+        dt = (time.perf_counter() - t0) / 7
+        legs["rds"] = {"what": "RDS path (model/fmMonoBlock.py:238-296): 9,600 discriminator samples (40 ms of signal) per call, float64 "
+                               "kernels (channel / carrier band-pass, serial PLL, mixers, 247/960 resampler, RRC) + host CDR / frame sync; "
+                               "host buffers, wall clock", "ms_per_block": round(dt * 1e3, 3), "x_real_time": round(0.04 / dt, 1)}
+        rds.close()
+    except Exception as e:  # a side leg must not take the headline down
+        legs["rds"] = {"error": str(e)}
     # (6) what this box's memory system gives a pure streaming read, by the access methods the kernels use
     reads = {}
     for method, label in ((0, "global_load_dwordx4 non-temporal to registers"), (1, "LDS-DMA ring (the matrix-core kernels' method)")):

@@ -305,6 +305,55 @@ FMRX_API int fmrx_channels_process(fmrx_channels *c, const uint8_t *iq, float *a
 FMRX_API int fmrx_channels_process_dev(fmrx_channels *c, float *d_audio_f32, int16_t *d_pcm16, int pcm_policy, void *stream);
 
 /* ------------------------------------------------------------------ */
+/* RDS path                                          */
+/* ------------------------------------------------------------------ */
+/* The reference has this path only as a float64 Python / NumPy model: model/fmMonoBlock.py:238-296 on top of
+ * model/fmSupportLib.py (it never reached its C++).  Here: float64 HIP kernels for the signal chain -- 54-60 kHz channel
+ * band-pass, squarer + 114 kHz band-pass, PLL (ncoScale 0.5, phaseAdjust 3pi/8, bandwidth 0.002), I/Q mixers, rational
+ * resampler to sps x 2375 Hz, root-raised-cosine matched filter -- and host C++ for the bit recovery the model does in
+ * Python (CDR, Manchester, differential decoding, frame synchronisation).  Input: the discriminator output (fm_demod) of
+ * the front end, one block per call, state carried by the handle. */
+typedef struct fmrx_rds_params {
+    int if_Fs;    /* rate of fm_demod, Hz */
+    int taps;     /* band-pass filters: 151 (model/fmMonoBlock.py:114) */
+    int upsamp, decim; /* resampler: 247/960 (mode 0), 817/1920 (mode 2) (:74-75, :83-84) */
+    int sps;      /* samples per symbol at the resampler output: 26 / 43 */
+    int rrc_taps; /* 101 */
+} fmrx_rds_params;
+typedef struct fmrx_rds fmrx_rds;
+FMRX_API int fmrx_rds_mode_params(int mode, fmrx_rds_params *p);   /* the model defines RDS rates for modes 0 and 2 */
+FMRX_API int fmrx_rds_create(fmrx_rds **out, const fmrx_rds_params *p, size_t max_block, int device);
+FMRX_API int fmrx_rds_destroy(fmrx_rds *r);
+FMRX_API int fmrx_rds_reset(fmrx_rds *r);
+FMRX_API size_t fmrx_rds_n_out(const fmrx_rds *r, size_t n);   /* n*upsamp/decim */
+/* One block of fm_demod (host, n samples; n*upsamp % decim == 0) -> rrc_i / rrc_q [n_out] (matched-filter output, in-phase
+ * and quadrature; either may be NULL), bits [<= n_out/sps + 2] = the differentially decoded bits of this block, *n_bits,
+ * offset_type [8] = the last offset word the frame synchroniser recognised over the bits kept so far ("A", "B", "C",
+ * "C_apos", "D" or " "), exactly as model/fmMonoBlock.py:276-297 reports them per block. */
+FMRX_API int fmrx_rds_process(fmrx_rds *r, const float *fm_demod, size_t n, double *rrc_i, double *rrc_q, uint8_t *bits,
+                              size_t *n_bits, char *offset_type);
+/* the signal chain only, on a device-resident fm_demod (e.g. the pipeline's FMRX_TAP_DEMOD buffer); async on `stream` */
+FMRX_API int fmrx_rds_process_dev(fmrx_rds *r, const float *d_demod, size_t n, void *stream);
+#define FMRX_RDS_TAP_CHANNEL 0
+#define FMRX_RDS_TAP_CARRIER 1
+#define FMRX_RDS_TAP_PLL_I 2
+#define FMRX_RDS_TAP_PLL_Q 3
+#define FMRX_RDS_TAP_RESAMPLED_I 4
+#define FMRX_RDS_TAP_RRC_I 5
+#define FMRX_RDS_TAP_RRC_Q 6
+#define FMRX_RDS_TAP_PLL_STATE 7
+FMRX_API int fmrx_rds_read_tap(fmrx_rds *r, int which, double *out, size_t *n);
+/* the model's primitives on host buffers (float64): bandPass / impResponse (fmSupportLib.py:358, 376; Python argument
+ * order taps, Fs, ...), impulseResponseRootRaisedCosine (:251), CDR incl. Manchester decoding (:103-219; state4 =
+ * {pair[0], pair[1], start, prev_size} in/out), diff_decoding (:241), framesync (:30-100) */
+FMRX_API int fmrx_rds_band_pass(int taps, double Fs, double Fb, double Fe, double *h);
+FMRX_API int fmrx_rds_imp_response(int taps, double Fs, double Fc, double *h);
+FMRX_API int fmrx_rds_rrc(double Fs, int taps, double *h);
+FMRX_API int fmrx_rds_cdr(const double *x, size_t n, int sps, int block_count, double *state4, uint8_t *bits, size_t *n_bits);
+FMRX_API int fmrx_rds_diff_decode(const uint8_t *in, size_t n, uint8_t *out);
+FMRX_API int fmrx_rds_frame_sync(const uint8_t *bits, size_t n, char *offset_type, size_t *next_index);
+
+/* ------------------------------------------------------------------ */
 /* fused front end (the hot kernel) as a stage of its own               */
 /* ------------------------------------------------------------------ */
 /* Fused: u8 I/Q -> (u8-128)/128 -> rf low-pass FIR -> decimate, I and Q

@@ -122,6 +122,25 @@ _sig("fmrx_channels_reset", [_vp, _int])
 _sig("fmrx_channels_load_dev", [_vp, _vp, _vp])
 _sig("fmrx_channels_process", [_vp, _u8p, _vp, _vp, _int])
 _sig("fmrx_channels_process_dev", [_vp, _vp, _vp, _int, _vp])
+class RdsParams(C.Structure):
+    _fields_ = [("if_Fs", _int), ("taps", _int), ("upsamp", _int), ("decim", _int), ("sps", _int), ("rrc_taps", _int)]
+
+
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_sig("fmrx_rds_mode_params", [_int, C.POINTER(RdsParams)])
+_sig("fmrx_rds_create", [C.POINTER(_vp), C.POINTER(RdsParams), _sz, _int])
+_sig("fmrx_rds_destroy", [_vp])
+_sig("fmrx_rds_reset", [_vp])
+_sig("fmrx_rds_n_out", [_vp, _sz], _sz)
+_sig("fmrx_rds_process", [_vp, _f32p, _sz, _vp, _vp, _vp, C.POINTER(_sz), C.c_char_p])
+_sig("fmrx_rds_process_dev", [_vp, _vp, _sz, _vp])
+_sig("fmrx_rds_read_tap", [_vp, _int, _vp, C.POINTER(_sz)])
+_sig("fmrx_rds_band_pass", [_int, C.c_double, C.c_double, C.c_double, _f64p])
+_sig("fmrx_rds_imp_response", [_int, C.c_double, C.c_double, _f64p])
+_sig("fmrx_rds_rrc", [C.c_double, _int, _f64p])
+_sig("fmrx_rds_cdr", [_f64p, _sz, _int, _int, _f64p, _u8p, C.POINTER(_sz)])
+_sig("fmrx_rds_diff_decode", [_u8p, _sz, _u8p])
+_sig("fmrx_rds_frame_sync", [_u8p, _sz, C.c_char_p, C.POINTER(_sz)])
 _sig("fmrx_fe_fir_decim_u8", [_u8p, _sz, _f32p, _sz, _uint, _vp, _vp, _vp, _int])
 _sig("fmrx_fe_plan_create", [C.POINTER(_vp), _f32p, _sz, _uint])
 _sig("fmrx_fe_plan_destroy", [_vp])
@@ -490,6 +509,94 @@ class Channels:
 
     def process_dev(self, d_audio_ptr=None, d_pcm_ptr=None, wrap=True, stream=None):
         _check(lib.fmrx_channels_process_dev(self._h, d_audio_ptr, d_pcm_ptr, PCM_WRAP if wrap else PCM_SATURATE, stream))
+
+
+# --------------------------------------------------------------------------
+# RDS path: the model's names (model/fmSupportLib.py), float64
+# --------------------------------------------------------------------------
+RDS_TAPS = {"channel": 0, "carrier": 1, "pll_i": 2, "pll_q": 3, "resampled_i": 4, "rrc_i": 5, "rrc_q": 6, "pll_state": 7}
+
+
+def rdsBandPass(N_taps, Fs, Fb, Fe) -> np.ndarray:
+    """fmSupportLib.py:358 bandPass (Python argument order), float64."""
+    h = np.zeros(N_taps)
+    _check(lib.fmrx_rds_band_pass(N_taps, Fs, Fb, Fe, h))
+    return h
+
+
+def rdsImpResponse(N_taps, Fs, Fc) -> np.ndarray:
+    h = np.zeros(N_taps)
+    _check(lib.fmrx_rds_imp_response(N_taps, Fs, Fc, h))
+    return h
+
+
+def impulseResponseRootRaisedCosine(Fs, N_taps) -> np.ndarray:
+    h = np.zeros(N_taps)
+    _check(lib.fmrx_rds_rrc(Fs, N_taps, h))
+    return h
+
+
+def CDR(input1, rds_SPS, to_pass_on_state, block_count):
+    """fmSupportLib.py:103 CDR -> (Manchester-decoded bits, [pair, next_start, size])."""
+    x = np.ascontiguousarray(input1, np.float64)
+    st = np.array([to_pass_on_state[0][0], to_pass_on_state[0][1], to_pass_on_state[1], to_pass_on_state[2]], np.float64)
+    bits = np.zeros(len(x) // max(int(rds_SPS), 1) + 4, np.uint8)
+    n = _sz(0)
+    _check(lib.fmrx_rds_cdr(x, len(x), rds_SPS, block_count, st, bits, C.byref(n)))
+    return bits[:n.value].astype(np.float64), [st[:2].copy(), int(st[2]), int(st[3])]
+
+
+def diff_decoding(manch_data) -> np.ndarray:
+    b = np.ascontiguousarray(manch_data, np.uint8)
+    out = np.zeros(len(b), np.uint8)
+    _check(lib.fmrx_rds_diff_decode(b, len(b), out))
+    return out.astype(np.float64)
+
+
+def framesync(diff_data):
+    b = np.ascontiguousarray(diff_data, np.uint8)
+    off, idx = C.create_string_buffer(8), _sz(0)
+    _check(lib.fmrx_rds_frame_sync(b, len(b), off, C.byref(idx)))
+    return off.value.decode(), idx.value
+
+
+class Rds:
+    """The RDS chain of model/fmMonoBlock.py:238-296 on fm_demod blocks (fmrx_rds_*)."""
+
+    def __init__(self, mode=0, max_block=9600, device=0, params: RdsParams | None = None):
+        self.params = params if params is not None else RdsParams()
+        if params is None:
+            _check(lib.fmrx_rds_mode_params(mode, C.byref(self.params)))
+        self._h = _vp()
+        _check(lib.fmrx_rds_create(C.byref(self._h), C.byref(self.params), max_block, device))
+
+    def close(self):
+        if getattr(self, "_h", None) and lib is not None:
+            lib.fmrx_rds_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def reset(self):
+        _check(lib.fmrx_rds_reset(self._h))
+
+    def process(self, fm_demod):
+        x = _f32(fm_demod)
+        no = lib.fmrx_rds_n_out(self._h, len(x))
+        yi, yq = np.zeros(no), np.zeros(no)
+        bits, nb, off = np.zeros(no // max(self.params.sps, 1) + 4, np.uint8), _sz(0), C.create_string_buffer(8)
+        _check(lib.fmrx_rds_process(self._h, x, len(x), yi.ctypes.data, yq.ctypes.data, bits.ctypes.data, C.byref(nb), off))
+        return {"rrc_i": yi, "rrc_q": yq, "diff_bits": bits[:nb.value].copy(), "offset_type": off.value.decode()}
+
+    def process_dev(self, d_demod_ptr, n, stream=None):
+        _check(lib.fmrx_rds_process_dev(self._h, d_demod_ptr, n, stream))
+
+    def read_tap(self, name) -> np.ndarray:
+        n = _sz(0)
+        _check(lib.fmrx_rds_read_tap(self._h, RDS_TAPS[name], None, C.byref(n)))
+        out = np.zeros(n.value)
+        _check(lib.fmrx_rds_read_tap(self._h, RDS_TAPS[name], out.ctypes.data, C.byref(n)))
+        return out
 
 
 class FrontEndPlan:
