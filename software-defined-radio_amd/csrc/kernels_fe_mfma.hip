@@ -40,6 +40,8 @@
 #include "fmrx_internal.hpp"
 
 #include <cmath>
+#include <type_traits>
+#include <utility>
 
 namespace fmrx {
 namespace {
@@ -343,6 +345,13 @@ struct FuCfg {
     static constexpr int LDS_WAVE = RING + (DR + MIRROR) * 4;
 };
 
+// f(integral_constant<int, 0>{}), f(integral_constant<int, 1>{}), ... in order: a loop whose index is a compile-time constant
+template <class Fn, int... K>
+__device__ __forceinline__ void for_each_index(std::integer_sequence<int, K...>, Fn &&f)
+{
+    (f(std::integral_constant<int, K>{}), ...);
+}
+
 // tile slot u of the fused kernel: bytes [u*TILE - FRONT, (u+1)*TILE - FRONT) of the block into ring slot rs
 template <class C, class F>
 __device__ __forceinline__ void fu_dma_slot(const uint8_t *__restrict__ x, const uint8_t *__restrict__ hist_end, long n_bytes,
@@ -355,7 +364,8 @@ __device__ __forceinline__ void fu_dma_slot(const uint8_t *__restrict__ x, const
 // PF / DRF / KPTF override P / DR / KPT, DBG compiles parts out -- ablation variants (tools/fused_tune.py;
 // DESIGN.md section 5 quotes them), compiled and dispatched only in a -DFMRX_TUNING build (option fused_tune).  DBG bits: 1 = no audio
 // work at all, 2 = the audio MFMAs replaced by one v_fma each, 4 = no byte flip (wrong results, timing
-// only), 8 = audio stores compiled out.
+// only), 8 = audio stores compiled out, 128 = two of the three tap digits only, 256 = four of the six K-steps only (both: wrong results), 16 = per-phase clock stamps of every wave (s_memtime) written to the f32
+// audio buffer as 8 longs per wave (tools/fused_phases.py reads them; the audio output is not produced).
 template <int T, int D, int TA, int DA, int PF = 0, int DRF = 0, int DBG = 0, int KPTF = 0>
 __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
     const uint8_t *__restrict__ x, const uint8_t *__restrict__ hist_end, long n_bytes, const i4 *__restrict__ a_img,
@@ -423,6 +433,15 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
         }
     }
 
+    // DBG & 16: where a wave's time goes, phase by phase (shader clock, summed over its tiles)
+    long ph[6] = {0, 0, 0, 0, 0, 0};
+    long n_stamped = 0;
+    auto stamp = [&](float dep) -> long {
+        long c = 0;
+        if (DBG & 16) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c) : "v"(dep) : "memory");
+        return c;
+    };
+    const long run_start = stamp(0.0f);
     const int col = lane & 15, g = lane >> 4;
     const int lane_off = F::COL_BYTES * col + 16 * g;
     const float scale_hi = scale_lo * 65536.0f;
@@ -450,14 +469,15 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
     auto slice_load = [&]() {
         // pend_ws walks the window, 16 samples per group of K-steps; one wrap per slice thanks to the mirror
 #pragma unroll
-        for (int k = 0; k < C::KPT / 4; k++) xs[k] = *reinterpret_cast<const f4 *>(dring + pend_ws + 16 * k);   // < DR + MIRROR
+        for (int k = 0; k < C::KPT / 4; k++)
+            xs[k] = (DBG & 512) ? (f4){1.0f, 2.0f, 3.0f, 4.0f} : *reinterpret_cast<const f4 *>(dring + pend_ws + 16 * k);   // < DR + MIRROR
         pend_ws += 4 * C::KPT;
         pend_ws = pend_ws >= C::DR ? pend_ws - C::DR : pend_ws;
     };
     auto slice_mfma = [&]() {
 #pragma unroll
-        for (int ph = 0; ph < C::NPH; ph++)
-            if (pend_ph == ph) {
+        for (int ph = 0; ph < ((DBG & 2048) ? 1 : C::NPH); ph++)
+            if ((DBG & 2048) || pend_ph == ph) {   // DBG 2048: always the first slice's taps (no chain of compares; wrong results)
 #pragma unroll
                 for (int j = ph * C::KPT; j < (ph + 1) * C::KPT && j < C::AK; j++) {
                     const float xv = xs[(j - ph * C::KPT) / 4][j % 4];
@@ -470,37 +490,145 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
                 }
             }
     };
+    auto store_batch = [&]() {
+        const f4 y = y0 + y1;
+        const long ao = pend_a0 + 4 * g;                                         // this lane's 4 consecutive outputs
+        if ((DBG & (8 | 16)) && y[0] != 1234.5f) {
+        } else if (ao + 3 < n_audio) {
+            if (audio) *reinterpret_cast<f4 *>(audio + ao) = y;
+            if (pcm) {
+                using s4 = short __attribute__((ext_vector_type(4)));
+                *reinterpret_cast<s4 *>(pcm + ao) =
+                    (s4){pcm_pack(y[0], wrap), pcm_pack(y[1], wrap), pcm_pack(y[2], wrap), pcm_pack(y[3], wrap)};
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (ao + k < n_audio) {
+                    if (audio) audio[ao + k] = y[k];
+                    if (pcm) pcm[ao + k] = pcm_pack(y[k], wrap);
+                }
+        }
+    };
     auto slice_done = [&]() {
         pend_ph++;
         if (pend_ph == C::NPH) {
-            const f4 y = y0 + y1;
-            const long ao = pend_a0 + 4 * g;                                         // this lane's 4 consecutive outputs
-            if ((DBG & 8) && y[0] != 1234.5f) {
-            } else if (ao + 3 < n_audio) {
-                if (audio) *reinterpret_cast<f4 *>(audio + ao) = y;
-                if (pcm) {
-                    using s4 = short __attribute__((ext_vector_type(4)));
-                    *reinterpret_cast<s4 *>(pcm + ao) =
-                        (s4){pcm_pack(y[0], wrap), pcm_pack(y[1], wrap), pcm_pack(y[2], wrap), pcm_pack(y[3], wrap)};
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (ao + k < n_audio) {
-                        if (audio) audio[ao + k] = y[k];
-                        if (pcm) pcm[ao + k] = pcm_pack(y[k], wrap);
-                    }
-            }
+            store_batch();
             pend = false;
         }
     };
+    // a finished batch becomes the pending one: batch bt = audio outputs [256 bt, 256 bt + 256) is in the ring, column
+    // `col` starts at discriminator sample DA*(256 bt + 16 col) - (TA-1); this lane reads samples 4g..4g+3 of every 16
+    auto begin_batch = [&](int bt) {
+        pend = true;
+        pend_ph = 0;
+        pend_a0 = static_cast<long>(bt) * C::AB_OUT + 16 * col;
+        int sb = (bt * C::AB_OUT * DA - (TA - 1)) - (C::TILE_OUT * tb - C::TILE_OUT);   // wave-uniform, >= 0
+        pend_ws = (sb + 16 * col * DA + 4 * g) % C::DR;
+        y0 = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+        y1 = y0;
+    };
+    // ---- interior batches run as straight-line code, one batch of TB tiles per loop iteration: every DMA is a steady
+    //      one inside the block, no tile touches the block's tail, the slices of the previous batch ride on tiles
+    //      0..NPH-1 with their taps selected at compile time.  A wave's time per tile is mostly a chain of dependent
+    //      issue (profiles/round2/04_fused_kernel_ab.txt): the general loop below spends a fifth of it on its ~25
+    //      scalar branches per tile.  Tiles [tb, t_fast0) and [t_fast1, t1) stay with the general loop. --------------
+    int t_fast1 = 0;                                               // first tile that is not in a straight-line batch
+    if (!(DBG & 4096)) {
+        long lim = t1 - C::P - 1;                                  // steady DMA: tile t + P + 1 <= t1 ...
+        const long in_x = (n_bytes - C::NP * 1024L + F::FRONT) / C::TILE_BYTES - C::P - 1;   // ... read whole from the block
+        lim = lim < in_x ? lim : in_x;
+        const long no_tail = (n_out - tail_keep) / C::TILE_OUT - 1;   // (t+1)*128 <= n_out - tail_keep
+        lim = lim < no_tail ? lim : no_tail;                       // tiles t <= lim qualify
+        t_fast1 = lim + 1 >= C::TB ? static_cast<int>((lim + 1) / C::TB) * C::TB : 0;
+    }
+    auto fast_tile = [&](auto kc, int t) {
+        constexpr int k = decltype(kc)::value;                     // tile k of its batch
+        {
+            const uint8_t *src = x + (static_cast<long>(t + C::P + 1) * C::TILE_BYTES - F::FRONT);   // wave-uniform
+            uint8_t *dst = ring + fill * C::TILE_BYTES;
+#pragma unroll
+            for (int q = 0; q < C::NP; q++)
+                if (q < C::NPF || lane < C::REM_LANES)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (lane * 16 + q * 1024)),
+                                                     (__attribute__((address_space(3))) void *)(dst + q * 1024), 16, 0, 0);
+        }
+        wait_vmcnt<C::YOUNGER>();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        i4 b[F::KSTEPS];
+        if (slot != C::NSLOT - 1) {
+            const uint8_t *bsrc = ring + slot * C::TILE_BYTES + lane_off;
+#pragma unroll
+            for (int j = 0; j < F::KSTEPS; j++) b[j] = *reinterpret_cast<const i4 *>(bsrc + 64 * j);
+        } else {
+#pragma unroll
+            for (int j = 0; j < F::KSTEPS; j++) b[j] = *reinterpret_cast<const i4 *>(ring + wrap_adr[j]);
+        }
+        if constexpr (k < C::NPH) slice_load();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        i4 acc[F::NDIG];
+#pragma unroll
+        for (int d = 0; d < F::NDIG; d++) acc[d] = (i4){0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < F::KSTEPS; j++) {
+            const i4 bs = b[j] ^ static_cast<int>(0x80808080u);
+#pragma unroll
+            for (int d = 0; d < F::NDIG; d++) acc[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[j][d], bs, acc[d], 0, 0, 0);
+        }
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int lo = acc[0][q];
+            if (F::NDIG >= 2) lo += acc[1][q] * 256;
+            const float flo = static_cast<float>(lo) * scale_lo;
+            v[q] = F::NDIG >= 3 ? __builtin_fmaf(static_cast<float>(acc[2][q]), scale_hi, flo) : flo;
+        }
+        float pi = __shfl(v[2], src_lane, 64), pq = __shfl(v[3], src_lane, 64);
+        pi = lane == 0 ? ci : pi;
+        pq = lane == 0 ? cq : pq;
+        ci = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[2]), 63));
+        cq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[3]), 63));
+        const float d0 = demod_fast(v[0], v[1], pi, pq);
+        const float d1 = demod_fast(v[2], v[3], v[0], v[1]);
+        const int ol = F::COL_OUT * col + 2 * g;
+        *reinterpret_cast<f2 *>(dring + dpos + ol) = (f2){d0, d1};
+        if (dpos == 0 && ol < C::MIRROR) *reinterpret_cast<f2 *>(dring + C::DR + ol) = (f2){d0, d1};
+        slot = slot + 1 == C::NSLOT ? 0 : slot + 1;
+        fill = fill + 1 == C::NSLOT ? 0 : fill + 1;
+        dpos = dpos + C::TILE_OUT == C::DR ? 0 : dpos + C::TILE_OUT;
+        if constexpr (k < C::NPH) {
+#pragma unroll
+            for (int j = k * C::KPT; j < (k + 1) * C::KPT && j < C::AK; j++) {
+                const float xv = xs[(j - k * C::KPT) / 4][j % 4];
+                if (j & 1) y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(au[j], xv, y1, 0, 0, 0);
+                else y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(au[j], xv, y0, 0, 0, 0);
+            }
+            if constexpr (k == C::NPH - 1) store_batch();
+        }
+    };
     for (int t = tb;;) {
+        if (t >= t0 && t < t_fast1 && t % C::TB == 0 && (!pend || pend_ph == 0) && !(DBG & 1)) {
+            if (!pend) {
+                // nothing is pending in front of the run's first batch: a batch whose outputs are all out of range takes
+                // the place (it multiplies whatever finite numbers the ring holds and stores nothing)
+                begin_batch(t / C::TB);
+                pend_a0 = n_audio;
+            }
+            for (; t < t_fast1; t += C::TB) {
+                for_each_index(std::make_integer_sequence<int, C::TB>{}, [&](auto kc) { fast_tile(kc, t + decltype(kc)::value); });
+                begin_batch(t / C::TB);
+            }
+        }
         const bool have_tile = t < t1;
         bool completed = false;
         if (have_tile) {
             const bool sl = pend;                                  // a slice of the pending batch rides along (wave-uniform)
             // keep P+1 tiles in flight behind this one: the slot of tile t-1 is free (its reads were waited for)
             const bool steady = t + C::P + 1 <= t1;
+            const long ta = stamp(ci);
             if (steady) fu_dma_slot<C, F>(x, hist_end, n_bytes, t + C::P + 1, ring, fill, lane);
             // tile t's slot and the first piece of slot t+1 have landed (vmcnt counts in issue order; the
             // occasional output stores are not credited, which only waits longer)
@@ -508,6 +636,7 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
             else wait_vmcnt<0>();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            const long tb_ = stamp(ci);
 
             i4 b[F::KSTEPS];
             if (slot != C::NSLOT - 1) {                            // wave-uniform: the window cannot reach the ring's end
@@ -522,15 +651,17 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
             __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0): the slot may be refilled
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            const long tc = stamp(__builtin_bit_cast(float, b[0][0]));
 
             i4 acc[F::NDIG];
 #pragma unroll
             for (int d = 0; d < F::NDIG; d++) acc[d] = (i4){0, 0, 0, 0};
 #pragma unroll
-            for (int j = 0; j < F::KSTEPS; j++) {
+            for (int j = 0; j < ((DBG & 256) ? F::KSTEPS - 2 : F::KSTEPS); j++) {
                 const i4 bs = (DBG & 4) ? b[j] : b[j] ^ static_cast<int>(0x80808080u);   // u8 ^ 0x80 = (u8 - 128) as int8
 #pragma unroll
-                for (int d = 0; d < F::NDIG; d++) acc[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[j][d], bs, acc[d], 0, 0, 0);
+                for (int d = 0; d < ((DBG & 128) ? F::NDIG - 1 : F::NDIG); d++)
+                    acc[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[j][d], bs, acc[d], 0, 0, 0);
             }
             float v[4];
 #pragma unroll
@@ -540,6 +671,7 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
                 const float flo = static_cast<float>(lo) * scale_lo;
                 v[k] = F::NDIG >= 3 ? __builtin_fmaf(static_cast<float>(acc[2][k]), scale_hi, flo) : flo;
             }
+            const long td = stamp(v[0] + v[1] + v[2] + v[3]);
             float pi = __shfl(v[2], src_lane, 64), pq = __shfl(v[3], src_lane, 64);
             if (lane == 0) {
                 pi = ci;
@@ -562,6 +694,7 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
                 if (prev_out && o + 2 == n_out) *prev_out = make_float2(v[2], v[3]);
                 if (prev_out && o + 1 == n_out) *prev_out = make_float2(v[0], v[1]);
             }
+            const long te = stamp(d0 + d1);
             slot = slot + 1 == C::NSLOT ? 0 : slot + 1;
             fill = fill + 1 == C::NSLOT ? 0 : fill + 1;
             dpos = dpos + C::TILE_OUT == C::DR ? 0 : dpos + C::TILE_OUT;
@@ -570,6 +703,15 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
             if (sl) {
                 slice_mfma();
                 slice_done();
+            }
+            if (DBG & 16) {
+                const long tf = stamp(ci);   // issue time: the slice's MFMAs run on under the next tile
+                ph[0] += tb_ - ta;
+                ph[1] += tc - tb_;
+                ph[2] += td - tc;
+                ph[3] += te - td;
+                ph[4] += tf - te;
+                n_stamped++;
             }
             completed = !(DBG & 1) && t >= t0 && ((t + 1) % C::TB == 0 || t + 1 == n_tiles);
             t++;
@@ -582,19 +724,21 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
             slice_mfma();
             slice_done();
         }
-        if (completed) {
-            // batch bt = audio outputs [256 bt, 256 bt + 256) is in the ring: column `col` starts at
-            // discriminator sample DA*(256 bt + 16 col) - (TA-1); this lane reads samples 4g..4g+3 of every 16
-            const int bt = (t - 1) / C::TB;
-            pend = true;
-            pend_ph = 0;
-            pend_a0 = static_cast<long>(bt) * C::AB_OUT + 16 * col;
-            int sb = (bt * C::AB_OUT * DA - (TA - 1)) - (C::TILE_OUT * tb - C::TILE_OUT);   // wave-uniform, >= 0
-            pend_ws = (sb + 16 * col * DA + 4 * g) % C::DR;
-            y0 = (f4){0.0f, 0.0f, 0.0f, 0.0f};
-            y1 = y0;
-        }
+        if (completed) begin_batch((t - 1) / C::TB);
         if (!have_tile && !pend) break;
+    }
+    if (DBG & 1024) {   // keep the audio taps' registers occupied for the whole run (with DBG & 1: nothing else uses them)
+        float keep = 0.0f;
+#pragma unroll
+        for (int j = 0; j < C::AK; j++) keep += au[j];
+        if (keep == 12345.678f && pcm) pcm[0] = 1;
+    }
+    if ((DBG & 16) && audio && lane == 0) {
+        long *rec = reinterpret_cast<long *>(audio) + 8L * wid;
+        for (int k = 0; k < 5; k++) rec[k] = ph[k];
+        rec[5] = stamp(0.0f) - run_start;
+        rec[6] = n_stamped;
+        rec[7] = run_start;
     }
 }
 
@@ -742,7 +886,7 @@ int mono_fused_launch(const FePlan &fe, const AudioPlan &au, const uint8_t *d_iq
         return launch_fused_mono<101, 10, 101, 5, P_, DR_, G_, K_>(fe, au, d_iq, n_samples, d_hist, d_prev, d_dhist_end,    \
                                                                   d_demod_tail, tail_keep, d_prev_out, d_audio, d_pcm, wrap, \
                                                                   d_hist_next, o, stream);
-        Y(2, 2, 0, 0, 0) Y(12, 2, 0, 1, 0) Y(1, 1, 0, 0, 0) Y(82, 2, 0, 8, 0) Y(102, 2, 0, 10, 0)
+        Y(2, 2, 0, 0, 0) Y(12, 2, 0, 1, 0) Y(1, 1, 0, 0, 0) Y(82, 2, 0, 8, 0) Y(102, 2, 0, 10, 0) Y(162, 2, 0, 16, 0) Y(224, 2, 0, 0, 24) Y(324, 3, 0, 0, 24) Y(216, 2, 0, 0, 16) Y(212, 2, 0, 0, 12) Y(20482, 2, 0, 2048, 0) Y(262, 2, 0, 26, 0) Y(172, 2, 0, 17, 0) Y(10252, 2, 0, 1025, 0) Y(5222, 2, 0, 522, 0) Y(5122, 2, 0, 512, 0) Y(22, 2, 0, 2, 0) Y(42, 2, 0, 4, 0) Y(1282, 2, 0, 128, 0) Y(2562, 2, 0, 256, 0) Y(3842, 2, 0, 384, 0) Y(3852, 2, 0, 385, 0) Y(40962, 2, 0, 4096, 0)
 #undef Y
     }
 #endif

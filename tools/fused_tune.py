@@ -16,9 +16,11 @@ na = pl.n_audio(n_bytes)
 d_a = torch.empty(na, dtype=torch.float32, device="cuda"); d_p = torch.empty(na, dtype=torch.int16, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
 def run(k):
+    global F32
     for _ in range(k):
-        pl.process_dev(d_iq.data_ptr(), n_bytes, d_a.data_ptr(), d_p.data_ptr(), stream=s)
+        pl.process_dev(d_iq.data_ptr(), n_bytes, d_a.data_ptr() if F32 else 0, d_p.data_ptr(), stream=s)
     torch.cuda.synchronize()
+F32 = os.environ.get("FUSED_TUNE_F32", "0") == "1"   # also write the f32 audio (round 1's output format)
 variants = sys.argv[1:] or ["2", "12", "3", "13", "4"]
 run(3000)   # settle
 res = {}
