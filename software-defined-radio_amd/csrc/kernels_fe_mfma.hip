@@ -492,7 +492,8 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
     };
     auto store_batch = [&]() {
         const f4 y = y0 + y1;
-        const long ao = pend_a0 + 4 * g;                                         // this lane's 4 consecutive outputs
+        long ao = pend_a0 + 4 * g;                                               // this lane's 4 consecutive outputs
+        if ((DBG & 32768) && ao + 3 < n_audio) ao = wid * 256L + 16 * col + 4 * g;   // every batch of a wave to one place (timing only)
         if ((DBG & (8 | 16)) && y[0] != 1234.5f) {
         } else if (ao + 3 < n_audio) {
             if (audio) *reinterpret_cast<f4 *>(audio + ao) = y;
@@ -533,18 +534,38 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
     //      0..NPH-1 with their taps selected at compile time.  A wave's time per tile is mostly a chain of dependent
     //      issue (profiles/round2/04_fused_kernel_ab.txt): the general loop below spends a fifth of it on its ~25
     //      scalar branches per tile.  Tiles [tb, t_fast0) and [t_fast1, t1) stay with the general loop. --------------
-    int t_fast1 = 0;                                               // first tile that is not in a straight-line batch
+    int t_fast1 = 0;                                               // first tile that is not in a straight-line steady batch
+    bool fast_last = false;                                        // the run's last batch [t1 - TB, t1) runs straight-line too
     if (!(DBG & 4096)) {
-        long lim = t1 - C::P - 1;                                  // steady DMA: tile t + P + 1 <= t1 ...
-        const long in_x = (n_bytes - C::NP * 1024L + F::FRONT) / C::TILE_BYTES - C::P - 1;   // ... read whole from the block
-        lim = lim < in_x ? lim : in_x;
-        const long no_tail = (n_out - tail_keep) / C::TILE_OUT - 1;   // (t+1)*128 <= n_out - tail_keep
+        // tile t may issue the DMA of tile t + P + 1 without looking if that tile is read whole from the block ...
+        const long in_x = (n_bytes - C::NP * 1024L + F::FRONT) / C::TILE_BYTES;              // last such tile
+        const long no_tail = (n_out - tail_keep) / C::TILE_OUT - 1;                          // ... (t+1)*128 <= n_out - tail_keep
+        long lim = t1 - C::P - 1;                                  // ... and tile t + P + 1 <= t1 (this wave's to fetch)
+        lim = lim < in_x - C::P - 1 ? lim : in_x - C::P - 1;
         lim = lim < no_tail ? lim : no_tail;                       // tiles t <= lim qualify
         t_fast1 = lim + 1 >= C::TB ? static_cast<int>((lim + 1) / C::TB) * C::TB : 0;
+        fast_last = t1 % C::TB == 0 && t1 - C::TB >= t0 && t1 <= in_x && t1 - 1 <= no_tail;
     }
-    auto fast_tile = [&](auto kc, int t) {
+    auto fast_tile = [&](auto kc, auto lastc, int t) {
         constexpr int k = decltype(kc)::value;                     // tile k of its batch
-        {
+        // the run's last batch: the tiles behind it belong to the next wave, only tile t1's head is fetched
+        constexpr bool STEADY = !decltype(lastc)::value || k + C::P + 1 <= C::TB;
+        constexpr int WAIT = STEADY ? C::YOUNGER : (C::NP - 1) + C::NP * (C::TB - k - 1);
+        constexpr bool EARLY_SLICE = (DBG & 8192) != 0;
+        auto slice_k = [&]() {
+#pragma unroll
+            for (int j = k * C::KPT; j < (k + 1) * C::KPT && j < C::AK; j++) {
+                const float xv = xs[(j - k * C::KPT) / 4][j % 4];
+                if (DBG & 2) {
+                    y0[j & 3] += xv * au[j];
+                    continue;
+                }
+                if (j & 1) y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(au[j], xv, y1, 0, 0, 0);
+                else y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(au[j], xv, y0, 0, 0, 0);
+            }
+        };
+        const long ta = stamp(ci);
+        if constexpr (STEADY) {
             const uint8_t *src = x + (static_cast<long>(t + C::P + 1) * C::TILE_BYTES - F::FRONT);   // wave-uniform
             uint8_t *dst = ring + fill * C::TILE_BYTES;
 #pragma unroll
@@ -553,9 +574,10 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (lane * 16 + q * 1024)),
                                                      (__attribute__((address_space(3))) void *)(dst + q * 1024), 16, 0, 0);
         }
-        wait_vmcnt<C::YOUNGER>();
+        wait_vmcnt<WAIT>();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        const long tb_ = stamp(ci);
         i4 b[F::KSTEPS];
         if (slot != C::NSLOT - 1) {
             const uint8_t *bsrc = ring + slot * C::TILE_BYTES + lane_off;
@@ -569,6 +591,7 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        const long tc = stamp(__builtin_bit_cast(float, b[0][0]));
         i4 acc[F::NDIG];
 #pragma unroll
         for (int d = 0; d < F::NDIG; d++) acc[d] = (i4){0, 0, 0, 0};
@@ -578,6 +601,9 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
 #pragma unroll
             for (int d = 0; d < F::NDIG; d++) acc[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[j][d], bs, acc[d], 0, 0, 0);
         }
+        // the slice's f32 MFMAs directly behind the front end's: the unpack / discriminator instructions below issue
+        // between them (one MFMA occupies the matrix pipe for 8 issue slots)
+        if constexpr (k < C::NPH && EARLY_SLICE) slice_k();
         float v[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -586,6 +612,7 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
             const float flo = static_cast<float>(lo) * scale_lo;
             v[q] = F::NDIG >= 3 ? __builtin_fmaf(static_cast<float>(acc[2][q]), scale_hi, flo) : flo;
         }
+        const long td = stamp(v[0] + v[1] + v[2] + v[3]);
         float pi = __shfl(v[2], src_lane, 64), pq = __shfl(v[3], src_lane, 64);
         pi = lane == 0 ? ci : pi;
         pq = lane == 0 ? cq : pq;
@@ -596,21 +623,36 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
         const int ol = F::COL_OUT * col + 2 * g;
         *reinterpret_cast<f2 *>(dring + dpos + ol) = (f2){d0, d1};
         if (dpos == 0 && ol < C::MIRROR) *reinterpret_cast<f2 *>(dring + C::DR + ol) = (f2){d0, d1};
+        if constexpr (k < C::NPH && EARLY_SLICE && (DBG & 16384)) {
+#pragma unroll
+            for (int i = 0; i < F::KSTEPS * F::NDIG; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < C::KPT; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+            }
+        }
+        const long te = stamp(d0 + d1);
         slot = slot + 1 == C::NSLOT ? 0 : slot + 1;
         fill = fill + 1 == C::NSLOT ? 0 : fill + 1;
         dpos = dpos + C::TILE_OUT == C::DR ? 0 : dpos + C::TILE_OUT;
-        if constexpr (k < C::NPH) {
-#pragma unroll
-            for (int j = k * C::KPT; j < (k + 1) * C::KPT && j < C::AK; j++) {
-                const float xv = xs[(j - k * C::KPT) / 4][j % 4];
-                if (j & 1) y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(au[j], xv, y1, 0, 0, 0);
-                else y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(au[j], xv, y0, 0, 0, 0);
-            }
-            if constexpr (k == C::NPH - 1) store_batch();
+        if constexpr (k < C::NPH && !EARLY_SLICE) slice_k();
+        if constexpr (k == C::NPH - 1) store_batch();
+        if (DBG & 16) {
+            const long tf = stamp(ci);   // issue time: the slice's MFMAs run on under the next tile
+            ph[0] += tb_ - ta;
+            ph[1] += tc - tb_;
+            ph[2] += td - tc;
+            ph[3] += te - td;
+            ph[4] += tf - te;
+            n_stamped++;
         }
     };
     for (int t = tb;;) {
-        if (t >= t0 && t < t_fast1 && t % C::TB == 0 && (!pend || pend_ph == 0) && !(DBG & 1)) {
+        if (t >= t0 && (t < t_fast1 || (fast_last && t == t1 - C::TB)) && t % C::TB == 0 && (!pend || pend_ph == 0) && !(DBG & 1)) {
             if (!pend) {
                 // nothing is pending in front of the run's first batch: a batch whose outputs are all out of range takes
                 // the place (it multiplies whatever finite numbers the ring holds and stores nothing)
@@ -618,8 +660,15 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
                 pend_a0 = n_audio;
             }
             for (; t < t_fast1; t += C::TB) {
-                for_each_index(std::make_integer_sequence<int, C::TB>{}, [&](auto kc) { fast_tile(kc, t + decltype(kc)::value); });
+                for_each_index(std::make_integer_sequence<int, C::TB>{},
+                               [&](auto kc) { fast_tile(kc, std::false_type{}, t + decltype(kc)::value); });
                 begin_batch(t / C::TB);
+            }
+            if (fast_last && t == t1 - C::TB) {
+                for_each_index(std::make_integer_sequence<int, C::TB>{},
+                               [&](auto kc) { fast_tile(kc, std::true_type{}, t + decltype(kc)::value); });
+                begin_batch(t / C::TB);
+                t += C::TB;
             }
         }
         const bool have_tile = t < t1;
@@ -886,7 +935,7 @@ int mono_fused_launch(const FePlan &fe, const AudioPlan &au, const uint8_t *d_iq
         return launch_fused_mono<101, 10, 101, 5, P_, DR_, G_, K_>(fe, au, d_iq, n_samples, d_hist, d_prev, d_dhist_end,    \
                                                                   d_demod_tail, tail_keep, d_prev_out, d_audio, d_pcm, wrap, \
                                                                   d_hist_next, o, stream);
-        Y(2, 2, 0, 0, 0) Y(12, 2, 0, 1, 0) Y(1, 1, 0, 0, 0) Y(82, 2, 0, 8, 0) Y(102, 2, 0, 10, 0) Y(162, 2, 0, 16, 0) Y(224, 2, 0, 0, 24) Y(324, 3, 0, 0, 24) Y(216, 2, 0, 0, 16) Y(212, 2, 0, 0, 12) Y(20482, 2, 0, 2048, 0) Y(262, 2, 0, 26, 0) Y(172, 2, 0, 17, 0) Y(10252, 2, 0, 1025, 0) Y(5222, 2, 0, 522, 0) Y(5122, 2, 0, 512, 0) Y(22, 2, 0, 2, 0) Y(42, 2, 0, 4, 0) Y(1282, 2, 0, 128, 0) Y(2562, 2, 0, 256, 0) Y(3842, 2, 0, 384, 0) Y(3852, 2, 0, 385, 0) Y(40962, 2, 0, 4096, 0)
+        Y(2, 2, 0, 0, 0) Y(12, 2, 0, 1, 0) Y(1, 1, 0, 0, 0) Y(82, 2, 0, 8, 0) Y(102, 2, 0, 10, 0) Y(162, 2, 0, 16, 0) Y(224, 2, 0, 0, 24) Y(324, 3, 0, 0, 24) Y(216, 2, 0, 0, 16) Y(212, 2, 0, 0, 12) Y(20482, 2, 0, 2048, 0) Y(262, 2, 0, 26, 0) Y(172, 2, 0, 17, 0) Y(10252, 2, 0, 1025, 0) Y(5222, 2, 0, 522, 0) Y(5122, 2, 0, 512, 0) Y(22, 2, 0, 2, 0) Y(42, 2, 0, 4, 0) Y(1282, 2, 0, 128, 0) Y(2562, 2, 0, 256, 0) Y(3842, 2, 0, 384, 0) Y(3852, 2, 0, 385, 0) Y(40962, 2, 0, 4096, 0) Y(327682, 2, 0, 32768, 0) Y(81922, 2, 0, 8192, 0) Y(245762, 2, 0, 24576, 0)
 #undef Y
     }
 #endif
