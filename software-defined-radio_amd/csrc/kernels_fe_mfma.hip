@@ -442,6 +442,8 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
         return c;
     };
     const long run_start = stamp(0.0f);
+    long rt_start = 0;
+    if (DBG & 16) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_start)::"memory");
     const int col = lane & 15, g = lane >> 4;
     const int lane_off = F::COL_BYTES * col + 16 * g;
     const float scale_hi = scale_lo * 65536.0f;
@@ -499,8 +501,9 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
             if (audio) *reinterpret_cast<f4 *>(audio + ao) = y;
             if (pcm) {
                 using s4 = short __attribute__((ext_vector_type(4)));
-                *reinterpret_cast<s4 *>(pcm + ao) =
-                    (s4){pcm_pack(y[0], wrap), pcm_pack(y[1], wrap), pcm_pack(y[2], wrap), pcm_pack(y[3], wrap)};
+                const s4 pk = (s4){pcm_pack(y[0], wrap), pcm_pack(y[1], wrap), pcm_pack(y[2], wrap), pcm_pack(y[3], wrap)};
+                if (DBG & 131072) __builtin_nontemporal_store(pk, reinterpret_cast<s4 *>(pcm + ao));
+                else *reinterpret_cast<s4 *>(pcm + ao) = pk;
             }
         } else {
 #pragma unroll
@@ -787,7 +790,9 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
         for (int k = 0; k < 5; k++) rec[k] = ph[k];
         rec[5] = stamp(0.0f) - run_start;
         rec[6] = n_stamped;
-        rec[7] = run_start;
+        long rt_end = 0;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_end)::"memory");
+        rec[7] = rt_end - rt_start;                                // 100 MHz ticks: rec[5] / rec[7] = shader clock / 100 MHz
     }
 }
 
@@ -805,20 +810,23 @@ int launch_fused_mono(const FePlan &fe, const AudioPlan &au, const uint8_t *d_iq
     const long n_batches = (n_audio + C::AB_OUT - 1) / C::AB_OUT;
     long wgs_per_cu = (160 * 1024) / (4L * C::LDS_WAVE);
     if (wgs_per_cu > 2) wgs_per_cu = 2;
+    // DBG 65536: one workgroup per CU (one wave per SIMD), forced by asking for more than half of the LDS
+    const int lds_bytes = (DBG & 65536) ? (4 * C::LDS_WAVE > 84 * 1024 ? 4 * C::LDS_WAVE : 84 * 1024) : 4 * C::LDS_WAVE;
+    if (DBG & 65536) wgs_per_cu = 1;
     const long max_waves = 256 * wgs_per_cu * 4;
     const long bpw = (n_batches + max_waves - 1) / max_waves;
     const long grid = ((n_batches + bpw - 1) / bpw + 3) / 4;
-    if (4 * C::LDS_WAVE > 64 * 1024) {   // more dynamic LDS than the default cap: opt in, once per device
+    if (lds_bytes > 64 * 1024) {   // more dynamic LDS than the default cap: opt in, once per device
         static bool raised[64] = {};
         int dev = 0;
         FMRX_HIP(hipGetDevice(&dev));
         if (dev < 0 || dev >= 64 || !raised[dev]) {
             FMRX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mono_fused_kernel<T, D, TA, DA, PF, DRF, DBG, KPTF>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 4 * C::LDS_WAVE));
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
             if (dev >= 0 && dev < 64) raised[dev] = true;
         }
     }
-    hipLaunchKernelGGL((mono_fused_kernel<T, D, TA, DA, PF, DRF, DBG, KPTF>), dim3(static_cast<unsigned>(grid)), dim3(256), 4 * C::LDS_WAVE, stream,
+    hipLaunchKernelGGL((mono_fused_kernel<T, D, TA, DA, PF, DRF, DBG, KPTF>), dim3(static_cast<unsigned>(grid)), dim3(256), lds_bytes, stream,
                        d_iq, d_hist + fe.hist_bytes, static_cast<long>(2 * n_samples), reinterpret_cast<const i4 *>(fe.a_img.p),
                        fe.scale_lo, au.mfma_table.p, reinterpret_cast<const float2 *>(d_prev), d_dhist_end, d_demod_tail,
                        tail_keep, reinterpret_cast<float2 *>(d_prev_out), d_audio, d_pcm, wrap, n_out, static_cast<int>(n_tiles),
@@ -935,7 +943,7 @@ int mono_fused_launch(const FePlan &fe, const AudioPlan &au, const uint8_t *d_iq
         return launch_fused_mono<101, 10, 101, 5, P_, DR_, G_, K_>(fe, au, d_iq, n_samples, d_hist, d_prev, d_dhist_end,    \
                                                                   d_demod_tail, tail_keep, d_prev_out, d_audio, d_pcm, wrap, \
                                                                   d_hist_next, o, stream);
-        Y(2, 2, 0, 0, 0) Y(12, 2, 0, 1, 0) Y(1, 1, 0, 0, 0) Y(82, 2, 0, 8, 0) Y(102, 2, 0, 10, 0) Y(162, 2, 0, 16, 0) Y(224, 2, 0, 0, 24) Y(324, 3, 0, 0, 24) Y(216, 2, 0, 0, 16) Y(212, 2, 0, 0, 12) Y(20482, 2, 0, 2048, 0) Y(262, 2, 0, 26, 0) Y(172, 2, 0, 17, 0) Y(10252, 2, 0, 1025, 0) Y(5222, 2, 0, 522, 0) Y(5122, 2, 0, 512, 0) Y(22, 2, 0, 2, 0) Y(42, 2, 0, 4, 0) Y(1282, 2, 0, 128, 0) Y(2562, 2, 0, 256, 0) Y(3842, 2, 0, 384, 0) Y(3852, 2, 0, 385, 0) Y(40962, 2, 0, 4096, 0) Y(327682, 2, 0, 32768, 0) Y(81922, 2, 0, 8192, 0) Y(245762, 2, 0, 24576, 0)
+        Y(2, 2, 0, 0, 0) Y(12, 2, 0, 1, 0) Y(1, 1, 0, 0, 0) Y(82, 2, 0, 8, 0) Y(102, 2, 0, 10, 0) Y(162, 2, 0, 16, 0) Y(224, 2, 0, 0, 24) Y(324, 3, 0, 0, 24) Y(216, 2, 0, 0, 16) Y(212, 2, 0, 0, 12) Y(20482, 2, 0, 2048, 0) Y(262, 2, 0, 26, 0) Y(172, 2, 0, 17, 0) Y(10252, 2, 0, 1025, 0) Y(5222, 2, 0, 522, 0) Y(5122, 2, 0, 512, 0) Y(22, 2, 0, 2, 0) Y(42, 2, 0, 4, 0) Y(1282, 2, 0, 128, 0) Y(2562, 2, 0, 256, 0) Y(3842, 2, 0, 384, 0) Y(3852, 2, 0, 385, 0) Y(40962, 2, 0, 4096, 0) Y(1310722, 2, 0, 131072, 0) Y(655362, 2, 0, 65536, 0) Y(655372, 2, 0, 65537, 0) Y(327682, 2, 0, 32768, 0) Y(81922, 2, 0, 8192, 0) Y(245762, 2, 0, 24576, 0)
 #undef Y
     }
 #endif
