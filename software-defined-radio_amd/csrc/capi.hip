@@ -50,6 +50,7 @@ bool option_ref(Options &o, const char *name, long **as_long, int **as_int)
     if (n == "fused_min_audio") *as_long = &o.fused_min_audio;
     else if (n == "fe_variant") *as_int = &o.fe_variant;
     else if (n == "resample_l2") *as_int = &o.resample_l2;
+    else if (n == "resample_exact") *as_int = &o.resample_exact;
     else if (n == "fe_wgs_per_cu") *as_int = &o.fe_wgs_per_cu;
     else if (n == "pll_warmup") *as_int = &o.pll_warmup;
     else if (n == "pll_segment") *as_int = &o.pll_segment;
@@ -70,6 +71,7 @@ Options &default_options()
         if (const char *e = std::getenv("FMRX_FE_VARIANT")) d.fe_variant = std::strcmp(e, "valu") == 0 ? 1 : 0;
         if (const char *e = std::getenv("FMRX_FUSED_MIN_AUDIO")) d.fused_min_audio = std::atol(e);
         if (std::getenv("FMRX_RESAMPLE_L2")) d.resample_l2 = 1;
+        if (const char *e = std::getenv("FMRX_RESAMPLE_EXACT")) d.resample_exact = std::atoi(e);
         if (const char *e = std::getenv("FMRX_FE_WGS_PER_CU")) d.fe_wgs_per_cu = std::atoi(e);
         if (const char *e = std::getenv("FMRX_PLL_WARMUP")) d.pll_warmup = std::atoi(e);
         if (const char *e = std::getenv("FMRX_PLL_SEGMENT")) d.pll_segment = std::atoi(e);
@@ -311,7 +313,7 @@ int fmrx_convolve_block_resample_fir(float *y, const float *x, size_t n, const f
     // the LDS-resident-table form from 65 536 outputs per call unless the option resample_l2 is set
     ResamplePlan plan;
     FMRX_TRY(resample_plan_init(plan, h, static_cast<int>(taps), static_cast<int>(decim), static_cast<int>(upsamp)));
-    FMRX_TRY(resample_launch(plan, s.a.p + Hp, n, 0, s.b.p, default_options(), nullptr, false));
+    FMRX_TRY(resample_launch(plan, s.a.p + Hp, n, 0, s.b.p, default_options(), nullptr, false, /*exact=*/true));
     FMRX_TRY(sync0());
     FMRX_TRY(d2h(y, s.b.p, n_out * sizeof(float)));
     // state refresh exactly as src/filter.cpp:218-222 (host copy): k = U-1; for

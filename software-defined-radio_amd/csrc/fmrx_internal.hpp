@@ -45,6 +45,8 @@ struct Options {
     int fe_variant = 0;            // "fe_variant" / FMRX_FE_VARIANT: 0 = matrix-core kernels ("mfma"), 1 = vector-ALU kernels ("valu")
     long fused_min_audio = 65536;  // "fused_min_audio" / FMRX_FUSED_MIN_AUDIO: audio samples per call from which the fused mono kernel runs
     int resample_l2 = 0;           // "resample_l2" / FMRX_RESAMPLE_L2: 1 = L2-table resampler kernel even for large calls
+    int resample_exact = 0;        // "resample_exact" / FMRX_RESAMPLE_EXACT: 1 = the pipeline's resampler keeps the reference's rounding sequence
+                                   //   (the bit-exact LDS-table kernel instead of the matrix-core one)
     int fe_wgs_per_cu = 0;         // "fe_wgs_per_cu" / FMRX_FE_WGS_PER_CU: cap on resident workgroups per CU of the front-end kernels (0 = auto)
     int pll_warmup = -1;           // "pll_warmup" / FMRX_PLL_WARMUP: warm-up samples per lane of the parallel PLL (-1 = built-in)
     int pll_segment = -1;          // "pll_segment" / FMRX_PLL_SEGMENT: samples per lane (-1 = built-in)
@@ -168,10 +170,18 @@ struct ResamplePlan {
     int npass = 0, W = 0, span_l = 0;
     DevBuf<float> table;       // polyphase-major taps [upsamp][JP]
     DevBuf<float> h;           // plain taps (generic path)
+    // matrix-core kernel (pipeline path): tap image [tile][lane][K-step], K index 0 of every tile, tile groups
+    bool mfma = false;
+    int mfma_ks4 = 0, mfma_ngroups = 0, mfma_pieces = 0;
+    DevBuf<float> mfma_img;
+    DevBuf<int> mfma_top, mfma_groups;   // per tile: K index 0's input offset; per group: m0, m1, lo, pieces
 };
 int resample_plan_init(ResamplePlan &pl, const float *h, int taps, int decim, int upsamp);
+// exact: only the kernels that keep the reference's rounding sequence (the primitive's contract)
+// d_pcm: also pack s16 PCM (d_y may then be null where resample_mfma_available(): that kernel writes either or both)
 int resample_launch(const ResamplePlan &pl, const float *d_x, size_t n_in, int delay, float *d_y, const Options &o,
-                    hipStream_t stream, bool force_generic);
+                    hipStream_t stream, bool force_generic, bool exact = false, int16_t *d_pcm = nullptr, int wrap = 0);
+bool resample_mfma_available(const ResamplePlan &pl, const float *d_x, size_t n_in, int delay, const Options &o);
 
 // ---- stereo band-pass pair (kernels_stereo.hip) ------------------------------------
 struct BpfPairPlan {

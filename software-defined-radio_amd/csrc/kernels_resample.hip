@@ -23,7 +23,19 @@
 // threads load their slice of W taps x all phases once and stream tiles of 1024 outputs past it.
 // A second pass continues every output's sum from where the first left it (the partial sum goes
 // through y as a float, so the rounding sequence -- j ascending -- is unchanged: still bit-exact).
+//
+// resample_mfma_kernel (pipeline path of modes 2/3, not the bit-exact primitive): the pattern of phases repeats
+// every U outputs = D inputs, so 16 consecutive outputs (rows) x 16 consecutive periods (columns) share one
+// banded tap matrix: a 16x16 output tile is  A[16 x K] * X[K x 16]  on the f32 matrix cores
+// (v_mfma_f32_16x16x4_f32), K = the inputs the 16 rows touch (15*D/U + J, 186 / 212 for modes 2 / 3), A resident
+// in registers, X = the periods' input windows staged once per workgroup in LDS.  Per output ~190 MACs are issued
+// instead of 101, but as 1/64 of a matrix instruction instead of a dependent chain with two LDS gathers per MAC.
+// The sum is an fma chain over the window (newest sample first, like the reference's j ascending) instead of
+// separately rounded products and sums: equal to float32 rounding (1e-7), not bit for bit.
+#include "device_math.hpp"
 #include "fmrx_internal.hpp"
+
+#include <algorithm>
 
 #pragma clang fp contract(off)
 
@@ -172,7 +184,203 @@ __global__ __launch_bounds__(kLT) void resample_lds_kernel(const float *__restri
     }
 }
 
+
+// ---- matrix-core resampler -----------------------------------------------------------------------------------
+// workgroup (pb, grp): periods [16 pb, 16 pb + 16) x the output tiles of group grp.  LDS: 16 rows (periods) of
+// `pieces` 16-byte pieces = inputs [lo, lo + 4 pieces) of each period (pieces odd: the rows then start on all 16
+// bank groups).  Tile m (rows = outputs 16m..16m+15 of a period): K index w <-> input offset top[m] - w.
+constexpr int kRsTiles = 4;                    // output tiles per workgroup: one per wave
+constexpr int kRsPieces = 160;                 // pieces per staged row at most (16 rows x 160 x 16 B = 40 KB)
+constexpr int kRsLoads = (kRsPieces + 15) / 16;
+
+// workgroup (pb, grp): periods [16 pb, 16 pb + 16) x output tiles [m0, m1) of group grp, wave w = tile m0 + w.
+// groups[4 grp ..] = m0, m1, lo, pieces: the 16 LDS rows hold inputs [lo, lo + 4 pieces) of each period (pieces odd: rows
+// then start on all 16 bank groups).  Tile m: K index w <-> input offset tile_top[m] - w inside the period.
+template <int KS4>
+__global__ __launch_bounds__(256) void resample_mfma_kernel(const float *__restrict__ x, long n_in, long g_min, long n_per,
+                                                             const float *__restrict__ a_tab, const int *__restrict__ tile_top,
+                                                             const int *__restrict__ groups, int n_groups, int decim,
+                                                             int upsamp, float *__restrict__ y, int16_t *__restrict__ pcm, int wrap)
+{
+    extern __shared__ __attribute__((aligned(16))) float rows[];
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    // workgroup id -> (period block, group): workgroups go round the 8 XCDs by id, so id % 8 is kept the same for all groups
+    // of a period block and they are adjacent in dispatch order: the overlap of their windows is served by one L2
+    const int blk = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    const int g_idx = blk % n_groups;
+    const long pb = static_cast<long>(blk / n_groups) * 8 + xcd;
+    const long q0 = pb * 16;
+    if (q0 >= n_per) return;
+    const int *grp = groups + 4 * g_idx;
+    const int m0 = grp[0], m1 = grp[1], lo = grp[2], pieces = grp[3];
+    const int stride = 4 * pieces;
+    const int m = m0 + wave;
+    const bool have = m < m1;                                  // wave-uniform
+    // this wave's taps first: their L2 round trip runs under the staging of the rows
+    f4 a[KS4];
+    {
+        const f4 *ap = reinterpret_cast<const f4 *>(a_tab) + (static_cast<long>(have ? m : m0) * 64 + lane) * KS4;
+#pragma unroll
+        for (int jj = 0; jj < KS4; jj++) a[jj] = ap[jj];
+    }
+    const int top = tile_top[have ? m : m0];
+    {
+        // 16 threads per row (period), every thread up to kRsLoads pieces, all loads in flight before the first LDS write
+        const int row = t >> 4, c = t & 15;
+        long q = q0 + row;
+        q = q < n_per ? q : n_per - 1;                       // columns past the end repeat the last period (never stored)
+        const long gr = q * decim + lo;
+        float *dst = rows + row * stride;
+        f4 v[kRsLoads];
+#pragma unroll
+        for (int u = 0; u < kRsLoads; u++) v[u] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+        if (q0 > 0 && q0 + 16 < n_per) {                     // no row reaches in front of the history or past the block
+#pragma unroll
+            for (int u = 0; u < kRsLoads; u++) {
+                const int pc = c + 16 * u;
+                if (pc < pieces) v[u] = *reinterpret_cast<const f4 *>(x + gr + 4 * pc);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < kRsLoads; u++) {
+                const int pc = c + 16 * u;
+                const long g = gr + 4 * pc;
+                if (pc < pieces) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[u][e] = (g + e >= g_min && g + e < n_in) ? x[g + e] : 0.0f;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kRsLoads; u++) asm volatile("" : "+v"(v[u]));   // every load issued before the first LDS write
+#pragma unroll
+        for (int u = 0; u < kRsLoads; u++) {
+            const int pc = c + 16 * u;
+            if (pc < pieces) *reinterpret_cast<f4 *>(dst + 4 * pc) = v[u];
+        }
+    }
+#pragma unroll
+    for (int jj = 0; jj < KS4; jj++) asm volatile("" : "+v"(a[jj]));   // the taps stay in registers (not re-loaded at their use)
+    __syncthreads();
+    if (!have) return;
+    const int n = lane & 15, kq = lane >> 4;
+    // this lane's operands of K-steps 4jj..4jj+3: inputs top - 16jj - 4kq - {0,1,2,3} of period n
+    const float *bp = rows + n * stride + (top - 3 - lo) - 4 * kq;
+    f4 acc = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int jj = 0; jj < KS4; jj++) {
+        const f4 xv = *reinterpret_cast<const f4 *>(bp - 16 * jj);
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj][e], xv[3 - e], acc, 0, 0, 0);
+    }
+    const long q = q0 + n;
+    if (q < n_per) {
+        const int r = 16 * m + 4 * kq;
+        const long o = q * upsamp + r;
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (r + e < upsamp) {
+                const float gq = acc[e] * static_cast<float>(upsamp);   // y += y*U (src/filter.cpp:221), separately rounded
+                const float out = acc[e] + gq;
+                if (y) y[o + e] = out;
+                if (pcm) pcm[o + e] = pcm_pack(out, wrap);              // src/threadMonoOnly.cpp:185-191
+            }
+    }
+}
+
 }  // namespace
+
+// host side of the matrix-core resampler: tile geometry, tap image, tile groups
+static int resample_mfma_plan(ResamplePlan &pl, const float *h)
+{
+    pl.mfma = false;
+    const int U = pl.upsamp, D = pl.decim, J = pl.J;
+    if (D % 4 != 0 || U < 16) return FMRX_OK;
+    const int ntiles = (U + 15) / 16;
+    std::vector<int> top(ntiles), b0(ntiles);
+    int K = 0;
+    for (int m = 0; m < ntiles; m++) {
+        const int r_last = std::min(16 * m + 15, U - 1);
+        const int bmax = static_cast<int>(static_cast<long>(r_last) * D / U);
+        b0[m] = static_cast<int>(static_cast<long>(16 * m) * D / U);
+        top[m] = (bmax + 1 + 3) / 4 * 4 - 1;
+        K = std::max(K, top[m] - b0[m] + J);
+    }
+    const int KS4 = (K + 15) / 16;
+    if (KS4 < 8 || KS4 > 16) return FMRX_OK;
+    // tile groups of kRsTiles consecutive tiles (one per wave): a period's staged window = what the group's tiles read
+    std::vector<int> grp;
+    int max_pieces = 0;
+    for (int m = 0; m < ntiles; m += kRsTiles) {
+        const int m1 = std::min(m + kRsTiles, ntiles);
+        const int lo = top[m] - 16 * KS4 + 1;                      // oldest input tile m reads; top % 4 == 3 -> a multiple of 4
+        int pieces = (top[m1 - 1] - lo + 1) / 4;
+        if (pieces % 2 == 0) pieces++;
+        if (pieces > kRsPieces) return FMRX_OK;
+        max_pieces = std::max(max_pieces, pieces);
+        grp.insert(grp.end(), {m, m1, lo, pieces});
+    }
+    // tap image [tile][lane][K-step]: lane (row i = lane & 15, kq = lane >> 4), K-step ks <-> K index w = 16 (ks/4) + 4 kq + ks%4
+    std::vector<float> img(static_cast<size_t>(ntiles) * 64 * 4 * KS4, 0.0f);
+    for (int m = 0; m < ntiles; m++)
+        for (int lane = 0; lane < 64; lane++) {
+            const int i = lane & 15, kq = lane >> 4, r = 16 * m + i;
+            if (r >= U) continue;
+            const long rd = static_cast<long>(r) * D;
+            const int ph = static_cast<int>(rd % U), bi = static_cast<int>(rd / U);
+            for (int ks = 0; ks < 4 * KS4; ks++) {
+                const int w = 16 * (ks / 4) + 4 * kq + ks % 4;
+                const int j = bi - (top[m] - w);
+                if (j >= 0 && j < J && ph + static_cast<long>(j) * U < pl.taps)
+                    img[(static_cast<size_t>(m) * 64 + lane) * 4 * KS4 + ks] = h[ph + j * U];
+            }
+        }
+    FMRX_TRY(pl.mfma_img.alloc(img.size()));
+    FMRX_HIP(hipMemcpy(pl.mfma_img.p, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
+    FMRX_TRY(pl.mfma_top.alloc(top.size()));
+    FMRX_HIP(hipMemcpy(pl.mfma_top.p, top.data(), top.size() * sizeof(int), hipMemcpyHostToDevice));
+    FMRX_TRY(pl.mfma_groups.alloc(grp.size()));
+    FMRX_HIP(hipMemcpy(pl.mfma_groups.p, grp.data(), grp.size() * sizeof(int), hipMemcpyHostToDevice));
+    pl.mfma_ks4 = KS4;
+    pl.mfma_ngroups = static_cast<int>(grp.size() / 4);
+    pl.mfma_pieces = max_pieces;
+    pl.mfma = true;
+    return FMRX_OK;
+}
+
+template <int KS4>
+static int resample_mfma_launch_ks(const ResamplePlan &pl, const float *x, size_t n_in, float *d_y, int16_t *d_pcm, int wrap,
+                                   hipStream_t stream)
+{
+    const long n_per = static_cast<long>(n_in / pl.decim);
+    const unsigned n_pb8 = static_cast<unsigned>((n_per + 127) / 128);   // period blocks, in eights
+    const size_t lds = static_cast<size_t>(16) * pl.mfma_pieces * 16;
+    hipLaunchKernelGGL(resample_mfma_kernel<KS4>, dim3(n_pb8 * 8 * pl.mfma_ngroups), dim3(256), lds, stream, x,
+                       static_cast<long>(n_in), -static_cast<long>(pl.J - 1), n_per, pl.mfma_img.p, pl.mfma_top.p,
+                       pl.mfma_groups.p, pl.mfma_ngroups, pl.decim, pl.upsamp, d_y, d_pcm, wrap);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FMRX_EHIP, "launch resample_mfma_kernel: %s", hipGetErrorString(e));
+    return FMRX_OK;
+}
+
+static int resample_mfma_launch(const ResamplePlan &pl, const float *x, size_t n_in, float *d_y, int16_t *d_pcm, int wrap,
+                                hipStream_t stream)
+{
+    switch (pl.mfma_ks4) {
+#define X(K_) case K_: return resample_mfma_launch_ks<K_>(pl, x, n_in, d_y, d_pcm, wrap, stream);
+        X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+#undef X
+    }
+    return fail(FMRX_EINVAL, "resample_mfma_launch: no kernel for %d K-steps", 4 * pl.mfma_ks4);
+}
+
+// whole periods, 16-byte aligned rows, enough periods to fill the chip: the matrix-core kernel may run
+bool resample_mfma_available(const ResamplePlan &pl, const float *d_x, size_t n_in, int delay, const Options &o)
+{
+    return pl.fast && pl.mfma && !o.resample_exact && n_in % pl.decim == 0 && n_in / pl.decim >= 64 &&
+           reinterpret_cast<uintptr_t>(d_x - delay) % 16 == 0;
+}
 
 int resample_plan_init(ResamplePlan &pl, const float *h, int taps, int decim, int upsamp)
 {
@@ -203,15 +411,23 @@ int resample_plan_init(ResamplePlan &pl, const float *h, int taps, int decim, in
             break;
         }
     }
-    return FMRX_OK;
+    return resample_mfma_plan(pl, h);
 }
 
 // x points at the block start; x[-(J-1+delay) .. -1] must be readable history
 int resample_launch(const ResamplePlan &pl, const float *d_x, size_t n_in, int delay, float *d_y, const Options &o,
-                    hipStream_t stream, bool force_generic)
+                    hipStream_t stream, bool force_generic, bool exact, int16_t *d_pcm, int wrap)
 {
     const size_t n_out = (n_in * static_cast<size_t>(pl.upsamp)) / pl.decim;
     if (n_out == 0) return FMRX_OK;
+    // the matrix-core kernel (float32-rounding-equal, not bit-exact: never for the primitive); it packs the PCM itself
+    if (!force_generic && !exact && resample_mfma_available(pl, d_x, n_in, delay, o))
+        return resample_mfma_launch(pl, d_x - delay, n_in, d_y, d_pcm, wrap, stream);
+    if (!d_y) return fail(FMRX_EINVAL, "resample_launch: this path needs the f32 output buffer");
+    if (d_pcm) {   // every other kernel writes f32 only: pack behind it
+        FMRX_TRY(resample_launch(pl, d_x, n_in, delay, d_y, o, stream, force_generic, exact, nullptr, 0));
+        return k_pcm16(d_y, n_out, d_pcm, wrap, stream);
+    }
     if (!pl.fast || force_generic)
         return k_resample_generic(d_x - delay, n_in, pl.h.p, pl.taps, pl.decim, pl.upsamp, d_y, stream);
     if (pl.npass > 0 && n_out >= 64 * kLT && !o.resample_l2) {

@@ -451,6 +451,19 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
     pl->last_mono = pl->mono.p;
     if (pl->channels == 1) {
         // ---- RF_MONO, modes 2/3: rational resampler (project.cpp:353) ----
+        if (!pl->force_generic && resample_mfma_available(pl->rs, demod, n_if, 0, pl->opt)) {
+            // the matrix-core kernel writes the caller's buffers itself; PCM-only callers get the reference's output
+            // format and nothing else (as the fused mono kernel of modes 0/1)
+            float *dst = d_audio_f32 ? d_audio_f32 : (d_pcm16 ? nullptr : pl->mono.p);
+            FMRX_TRY(resample_launch(pl->rs, demod, n_if, 0, dst, pl->opt, s, false, false, d_pcm16, pcm_policy));
+            pl->last_mono = dst;
+            if (prof) {
+                FMRX_HIP(hipEventRecord(ev[2], s));
+                FMRX_HIP(hipEventRecord(ev[3], s));
+                pl->calls++;
+            }
+            return FMRX_OK;
+        }
         FMRX_TRY(audio_stage(pl, demod, n_if, 0, pl->mono.p, s));
         if (prof) FMRX_HIP(hipEventRecord(ev[2], s));
     } else {
