@@ -467,6 +467,42 @@ def _run_blocks(pl, iq, bb, nblk):
     return outs
 
 
+@pytest.mark.parametrize("mode,periods", [(2, 64 + 13), (2, 400), (3, 64), (3, 171)])
+def test_resampler_matrix_core_kernel(fmrx, oracle, mode, periods):
+    """Pipeline path of modes 2 / 3 from 64 periods (64 x 800 / 3200 IF samples) per call: the polyphase resampler as f32
+    matrix-core tiles (16 outputs x 16 periods), which also packs the PCM.  Its sums are fma chains over the window instead
+    of the reference's separately rounded products and sums: equal to float32 rounding, not bit for bit -- compared here
+    with the bit-exact LDS-table kernel on the SAME discriminator output (option resample_exact), two consecutive calls
+    (carried history; period counts that are not multiples of the 16 a tile holds), then with the oracle end to end."""
+    import torch
+    p = fmrx.modeParams(mode)
+    n_if = periods * p.audio_decim
+    nb = 2 * n_if * p.rf_decim
+    iq = oracle.synth_fm_u8(nb, rf_Fs=p.rf_Fs, seed=77 + mode)
+    assert iq.size == 2 * nb
+    a, b, po = fmrx.Pipeline(mode, 1, max_block_bytes=nb), fmrx.Pipeline(mode, 1, max_block_bytes=nb), oracle.pipeline(mode, 1)
+    b.set_option("resample_exact", 1)
+    c = fmrx.Pipeline(mode, 1, max_block_bytes=nb)          # PCM only, device buffers
+    d_iq = torch.from_numpy(iq).cuda()
+    d_pcm = torch.empty(a.n_audio(nb), dtype=torch.int16, device="cuda")
+    for k in range(2):
+        blk = iq[k * nb:(k + 1) * nb]
+        oa, ob, ref = a.process(blk), b.process(blk), po.process(blk)
+        assert len(oa["audio"]) == periods * p.audio_upsamp
+        err = np.abs(oa["audio"].astype(np.float64) - ob["audio"])
+        # float32 rounding of a 101-term sum, in two orders: a few ulp of the peak at worst, 1e-7 of the signal in the RMS
+        assert err.max() <= 1e-6 * max(np.abs(ob["audio"]).max(), 1e-3), (k, err.max())
+        assert rel_rms(oa["audio"], ob["audio"]) <= 2e-7, rel_rms(oa["audio"], ob["audio"])
+        assert_pcm_close(oa["pcm16"], ob["pcm16"])
+        assert_audio_close(oa["audio"], ref["audio"], f"oracle, mode {mode} call {k}")
+        assert_pcm_close(oa["pcm16"], oracle.pcm16(ref["audio"]))
+        c.process_dev(d_iq.data_ptr() + k * nb, nb, None, d_pcm.data_ptr())
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(d_pcm.cpu().numpy(), oa["pcm16"])
+        with pytest.raises(fmrx.FmrxError):   # PCM-only call: no f32 audio was written anywhere
+            c.read_tap("mono_filt")
+
+
 FE_VARIANTS = ["mfma", "valu"]   # matrix-core kernels (default) / vector-ALU kernels (the north star's "no MFMA" form)
 
 
