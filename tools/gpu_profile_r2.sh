@@ -15,5 +15,6 @@ pmc pmc_sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
 pmc pmc_sq2 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
 pmc pmc_mfma SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_VALU_MFMA_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stereo -o stereo -- python3 tools/prof_stereo_r2.py > $OUT/stereo.log 2>&1; echo "stereo rc=$?"
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/modes23 -o m23 -- python3 tools/prof_modes23_r2.py > $OUT/modes23.log 2>&1 < /dev/null; echo "modes23 rc=$?"
 timeout -k 10 400 python3 bench.py > $OUT/bench_default.log 2>&1; echo "bench default rc=$?"
 tail -c 600 $OUT/bench_default.log

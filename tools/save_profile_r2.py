@@ -67,3 +67,9 @@ open(f"{dst}/02_stereo_step{tag}.txt", "w").write("\n".join(S) + "\n")
 for f in glob.glob(out + '/stereo/**/*kernel_stats.csv', recursive=True):
     shutil.copy(f, f"{dst}/02_stereo_step_kernel_stats{tag}.csv")
 print("\n".join(L)); print("\n".join(S))
+
+M = [f"# profiles/round2/08_modes23{tag}.txt -- MI355X, 1 GPU: kernel stats of modes 2 and 3 mono, 127 M-sample steps (2 x the bench legs' step), s16 out",
+     "rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/prof_modes23_r2.py"]
+M += stats(out + '/modes23/**/*kernel_stats.csv')
+if len(M) > 2:
+    open(f"{dst}/08_modes23{tag}.txt", "w").write("\n".join(M) + "\n")
