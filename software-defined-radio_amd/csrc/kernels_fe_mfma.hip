@@ -77,6 +77,13 @@ struct MfCfg {
     static_assert(YOUNGER + 2 * P <= 63, "vmcnt is 6 bits");
 };
 
+// f(integral_constant<int, 0>{}), f(integral_constant<int, 1>{}), ... in order: a loop whose index is a compile-time constant
+template <class Fn, int... K>
+__device__ __forceinline__ void for_each_index(std::integer_sequence<int, K...>, Fn &&f)
+{
+    (f(std::integral_constant<int, K>{}), ...);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt()
 {
@@ -123,7 +130,7 @@ __device__ __forceinline__ void mf_dma_tile(const uint8_t *__restrict__ x, const
 }
 
 // DBG (ablation variants, compiled and dispatched only in a -DFMRX_TUNING build: option fe_mfma_tune):
-// 1 = no output stores, 2 = no MFMA work, 8 = non-temporal DMA
+// 1 = no output stores, 2 = no MFMA work, 8 = non-temporal DMA, 16 = general tile loop only (no straight-line interior loop)
 template <int T, int D, int MINB, int PF, int DBG = 0>
 __global__ __launch_bounds__(256, MINB) void fe_mfma_kernel(
     const uint8_t *__restrict__ x, const uint8_t *__restrict__ hist_end, long n_bytes, const i4 *__restrict__ a_img,
@@ -185,7 +192,87 @@ __global__ __launch_bounds__(256, MINB) void fe_mfma_kernel(
     const bool with_if = y_if != nullptr;
     const int src_lane = lane >= 16 ? lane - 16 : lane + 47;   // who holds the output in front of this lane's first
     int slot = 0, fill = C::P;                                 // ring slot of this tile / of the tile P ahead
+    // ---- interior tiles as straight-line code, NSLOT tiles per loop iteration (ring slots are compile-time constants): the
+    //      DMA of the tile P ahead is known to lie inside the block, the tile is full, the counted wait is the steady one.
+    //      Same arithmetic as the general iteration below, minus its ~12 scalar branches per tile (the lesson of the fused
+    //      kernel: a wave's time per tile is a chain of dependent issue, profiles/round2/04_fused_kernel_ab.txt). ----------
+    auto fast_tile = [&](auto uc, auto modec, int t) {
+        constexpr int u = decltype(uc)::value;                 // ring slot of tile t; the tile P ahead goes to (u + P) % NSLOT
+        constexpr int MODE = decltype(modec)::value;           // 1 = discriminator output, 2 = IF output, 3 = both
+        constexpr int FILL = (u + C::P) % C::NSLOT;
+        {
+            const uint8_t *src = x + (static_cast<long>(t + C::P * tstep) * C::STRIDE_BYTES - C::LEAD);   // wave-uniform
+            uint8_t *dst = ring + FILL * C::SLOT;
+#pragma unroll
+            for (int q = 0; q < C::NP; q++)
+                if (q < C::NPF || lane < C::REM_LANES)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (lane * 16 + q * 1024)),
+                                                     (__attribute__((address_space(3))) void *)(dst + q * 1024), 16, 0, 0);
+        }
+        wait_vmcnt<C::YOUNGER + (MODE == 3 ? 2 : 1) * C::P>();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint8_t *bsrc = ring + u * C::SLOT + lane_off;
+        i4 b[C::KSTEPS];
+#pragma unroll
+        for (int j = 0; j < C::KSTEPS; j++) b[j] = *reinterpret_cast<const i4 *>(bsrc + 64 * j);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        i4 acc[C::NDIG];
+#pragma unroll
+        for (int d = 0; d < C::NDIG; d++) acc[d] = (i4){0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < C::KSTEPS; j++) {
+            const i4 bs = b[j] ^ static_cast<int>(0x80808080u);
+#pragma unroll
+            for (int d = 0; d < C::NDIG; d++) acc[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[j][d], bs, acc[d], 0, 0, 0);
+        }
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int lo = acc[0][k];
+            if (C::NDIG >= 2) lo += acc[1][k] * 256;
+            const float flo = static_cast<float>(lo) * scale_lo;
+            v[k] = C::NDIG >= 3 ? __builtin_fmaf(static_cast<float>(acc[2][k]), scale_hi, flo) : flo;
+        }
+        const long o = static_cast<long>(t) * C::TILE_OUT + C::COL_OUT * (col - 1) + 2 * g;
+        float d0 = 0.0f, d1 = 0.0f;
+        if constexpr ((MODE & 1) != 0) {
+            const float pi = __shfl(v[2], src_lane, 64), pq = __shfl(v[3], src_lane, 64);
+            d0 = demod_fast(v[0], v[1], pi, pq);
+            d1 = demod_fast(v[2], v[3], v[0], v[1]);
+        }
+        if (col > 0) {
+            if constexpr ((MODE & 1) != 0) *reinterpret_cast<f2 *>(demod + o) = (f2){d0, d1};
+            if constexpr ((MODE & 2) != 0) *reinterpret_cast<f4 *>(y_if + 2 * o) = (f4){v[0], v[1], v[2], v[3]};
+        }
+    };
+    // tiles tile, tile + tstep, ... of this wave that qualify: index it in [P, it_end) (it < P: the counted wait is another)
+    long it_end = 0;
+    // measured (tools/fe_mfma_tune_modes.py, whole step): D = 3 0.096 -> 0.084 ms, D = 5 0.041 -> 0.038 ms; D = 10 sits at the
+    // streaming rate of the LDS-DMA ring either way (0.0396 vs 0.0408 ms): general loop there
+    if (!(DBG & 16) && D < 10) {
+        const long nt = n_tiles, ts = tstep;
+        // (a) tile + P*tstep exists and its window is read whole from the block; (b) the tile's outputs and the pair behind exist
+        const long last_dma = (n_bytes - C::NP * 1024L + C::LEAD) / C::STRIDE_BYTES;   // last tile whose window fits
+        long lim = (nt - 1 < last_dma ? nt - 1 : last_dma) - C::P * ts;               // tile <= lim
+        const long full = (n_out - 2) / C::TILE_OUT - 1;                               // (tile+1)*TILE_OUT + 2 <= n_out
+        lim = lim < full ? lim : full;
+        it_end = lim >= tile ? (lim - tile) / ts + 1 : 0;
+    }
+    auto fast_loop = [&](auto modec, int &it) {
+        for (; it + C::NSLOT <= it_end; it += C::NSLOT, tile += C::NSLOT * tstep)
+            for_each_index(std::make_integer_sequence<int, C::NSLOT>{},
+                           [&](auto uc) { fast_tile(uc, modec, tile + decltype(uc)::value * tstep); });
+    };
     for (int it = 0; tile < n_tiles; tile += tstep, it++) {
+        if (it >= C::P && slot == 0 && it + C::NSLOT <= it_end && tile > 0) {
+            if (demod && with_if) fast_loop(std::integral_constant<int, 3>{}, it);
+            else if (demod) fast_loop(std::integral_constant<int, 1>{}, it);
+            else fast_loop(std::integral_constant<int, 2>{}, it);
+            if (tile >= n_tiles) break;
+        }
         const bool steady = tile + C::P * tstep < n_tiles;     // wave-uniform
         if (steady) mf_dma_tile<C, (DBG & 8) ? 2 : 0>(x, hist_end, n_bytes, tile + C::P * tstep, ring, fill, lane);
         // ---- this tile's window has landed -------------------------------------------------
@@ -344,13 +431,6 @@ struct FuCfg {
     static_assert(MIRROR <= TILE_OUT, "the mirror is refreshed by the tile at position 0");
     static constexpr int LDS_WAVE = RING + (DR + MIRROR) * 4;
 };
-
-// f(integral_constant<int, 0>{}), f(integral_constant<int, 1>{}), ... in order: a loop whose index is a compile-time constant
-template <class Fn, int... K>
-__device__ __forceinline__ void for_each_index(std::integer_sequence<int, K...>, Fn &&f)
-{
-    (f(std::integral_constant<int, K>{}), ...);
-}
 
 // tile slot u of the fused kernel: bytes [u*TILE - FRONT, (u+1)*TILE - FRONT) of the block into ring slot rs
 template <class C, class F>
@@ -895,6 +975,13 @@ int fe_mfma_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, cons
         return launch_mfma<101, 10, 2, 3, G_>(pl, d_iq, n_samples, d_hist, d_prev, d_demod, d_if, d_prev_out, d_hist_next, o, stream);
         Y(1) Y(2) Y(3) Y(8)
 #undef Y
+        if (pl.taps == 101 && v == 1600) {   // general loop only (A/B of the straight-line interior loop), any decimation
+#define Y(D_) \
+    if (pl.decim == D_) return launch_mfma<101, D_, 2, 0, 16>(pl, d_iq, n_samples, d_hist, d_prev, d_demod, d_if, d_prev_out, d_hist_next, o, stream, \
+                                                              d_dhist_src, d_dhist_dst, dhist_n);
+            Y(10) Y(5) Y(3)
+#undef Y
+        }
     }
 #endif
 #define X(T_, D_) \
