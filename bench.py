@@ -372,7 +372,8 @@ def side_legs(torch, fmrx, synth, args, pl, step, d_iq, n_bytes, stream) -> dict
         legs["rds"] = {"error": str(e)}
     # (6) what this box's memory system gives a pure streaming read, by the access methods the kernels use
     reads = {}
-    for method, label in ((0, "global_load_dwordx4 non-temporal to registers"), (1, "LDS-DMA ring (the matrix-core kernels' method)")):
+    for method, label in ((0, "global_load_dwordx4 non-temporal to registers"), (1, "LDS-DMA ring (the matrix-core kernels' method)"),
+                          (65, "LDS-DMA ring, 192 KiB chunks dealt round-robin over the waves (best pattern found, tools/stream_patterns.py)")):
         try:
             ms = event_ms(torch, lambda: fmrx.diagStreamRead(d_iq.data_ptr(), n_bytes, method, stream), 20, warm=20)
             reads[label] = round(n_bytes / (ms * 1e-3) / 1e9, 1)

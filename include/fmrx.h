@@ -159,8 +159,9 @@ FMRX_API int fmrx_pcm16(const float *audio, size_t n, int16_t *out, int wrap);
 FMRX_API int fmrx_diag_libm(int fn, const float *a, const float *b, size_t n, float *out);
 /* Measurement aid for bench.py: ONE pure streaming read of a device buffer (>= 3 MiB, 16-byte aligned) by
  * one of the access methods the front-end kernels use -- method 0: non-temporal global loads into
- * registers, 1: LDS-DMA ring -- asynchronous on `stream`; the caller times it (what the memory system gives
- * a read-only kernel, next to the nominal 8 TB/s). */
+ * registers, 1: LDS-DMA ring, one contiguous run per wave (the fused kernel's pattern), m >= 2: LDS-DMA ring, chunks of
+ * m - 1 steps of 3 KiB dealt round-robin over the waves -- asynchronous on `stream`; the caller times it (what the
+ * memory system gives a read-only kernel, next to the nominal 8 TB/s). */
 FMRX_API int fmrx_diag_stream_read_dev(const void *d_buf, size_t bytes, int method, void *stream);
 /* replaces estimatePSD  include/fourier.h, src/fourier.cpp:44-128 (with its DFT,
  * :15-23): Bartlett average, in dB, of Hann-windowed nfft-point spectra of

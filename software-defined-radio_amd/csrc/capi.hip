@@ -459,7 +459,7 @@ int fmrx_diag_libm(int fn, const float *a, const float *b, size_t n, float *out)
 
 int fmrx_diag_stream_read_dev(const void *d_buf, size_t bytes, int method, void *stream)
 {
-    if (!d_buf || (method != 0 && method != 1)) return fail(FMRX_EINVAL, "diag_stream_read_dev: bad arguments");
+    if (!d_buf || method < 0 || method > 4096) return fail(FMRX_EINVAL, "diag_stream_read_dev: bad arguments");
     FMRX_TRY(require_device());
     static thread_local DevBuf<unsigned> sink;
     FMRX_TRY(sink.ensure(4));

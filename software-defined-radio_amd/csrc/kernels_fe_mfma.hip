@@ -893,7 +893,8 @@ int launch_fused_mono(const FePlan &fe, const AudioPlan &au, const uint8_t *d_iq
     // DBG 65536: one workgroup per CU (one wave per SIMD), forced by asking for more than half of the LDS
     const int lds_bytes = (DBG & 65536) ? (4 * C::LDS_WAVE > 84 * 1024 ? 4 * C::LDS_WAVE : 84 * 1024) : 4 * C::LDS_WAVE;
     if (DBG & 65536) wgs_per_cu = 1;
-    const long max_waves = 256 * wgs_per_cu * 4;
+    // DBG 262144 / 524288: 2 x / 4 x as many, shorter runs (the workgroups then take turns on the CUs)
+    const long max_waves = 256 * wgs_per_cu * 4 * ((DBG & 262144) ? 2 : 1) * ((DBG & 524288) ? 4 : 1);
     const long bpw = (n_batches + max_waves - 1) / max_waves;
     const long grid = ((n_batches + bpw - 1) / bpw + 3) / 4;
     if (lds_bytes > 64 * 1024) {   // more dynamic LDS than the default cap: opt in, once per device
@@ -1030,7 +1031,7 @@ int mono_fused_launch(const FePlan &fe, const AudioPlan &au, const uint8_t *d_iq
         return launch_fused_mono<101, 10, 101, 5, P_, DR_, G_, K_>(fe, au, d_iq, n_samples, d_hist, d_prev, d_dhist_end,    \
                                                                   d_demod_tail, tail_keep, d_prev_out, d_audio, d_pcm, wrap, \
                                                                   d_hist_next, o, stream);
-        Y(2, 2, 0, 0, 0) Y(12, 2, 0, 1, 0) Y(1, 1, 0, 0, 0) Y(82, 2, 0, 8, 0) Y(102, 2, 0, 10, 0) Y(162, 2, 0, 16, 0) Y(224, 2, 0, 0, 24) Y(324, 3, 0, 0, 24) Y(216, 2, 0, 0, 16) Y(212, 2, 0, 0, 12) Y(20482, 2, 0, 2048, 0) Y(262, 2, 0, 26, 0) Y(172, 2, 0, 17, 0) Y(10252, 2, 0, 1025, 0) Y(5222, 2, 0, 522, 0) Y(5122, 2, 0, 512, 0) Y(22, 2, 0, 2, 0) Y(42, 2, 0, 4, 0) Y(1282, 2, 0, 128, 0) Y(2562, 2, 0, 256, 0) Y(3842, 2, 0, 384, 0) Y(3852, 2, 0, 385, 0) Y(40962, 2, 0, 4096, 0) Y(1310722, 2, 0, 131072, 0) Y(655362, 2, 0, 65536, 0) Y(655372, 2, 0, 65537, 0) Y(327682, 2, 0, 32768, 0) Y(81922, 2, 0, 8192, 0) Y(245762, 2, 0, 24576, 0)
+        Y(2, 2, 0, 0, 0) Y(12, 2, 0, 1, 0) Y(1, 1, 0, 0, 0) Y(82, 2, 0, 8, 0) Y(102, 2, 0, 10, 0) Y(162, 2, 0, 16, 0) Y(224, 2, 0, 0, 24) Y(324, 3, 0, 0, 24) Y(216, 2, 0, 0, 16) Y(212, 2, 0, 0, 12) Y(20482, 2, 0, 2048, 0) Y(262, 2, 0, 26, 0) Y(172, 2, 0, 17, 0) Y(10252, 2, 0, 1025, 0) Y(5222, 2, 0, 522, 0) Y(5122, 2, 0, 512, 0) Y(22, 2, 0, 2, 0) Y(42, 2, 0, 4, 0) Y(1282, 2, 0, 128, 0) Y(2562, 2, 0, 256, 0) Y(3842, 2, 0, 384, 0) Y(3852, 2, 0, 385, 0) Y(40962, 2, 0, 4096, 0) Y(2621442, 2, 0, 262144, 0) Y(5242882, 2, 0, 524288, 0) Y(1310722, 2, 0, 131072, 0) Y(655362, 2, 0, 65536, 0) Y(655372, 2, 0, 65537, 0) Y(327682, 2, 0, 32768, 0) Y(81922, 2, 0, 8192, 0) Y(245762, 2, 0, 24576, 0)
 #undef Y
     }
 #endif
