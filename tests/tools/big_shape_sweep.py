@@ -2,7 +2,7 @@
 """One-off check at scale: every fused-kernel shape and every front-end shape on a 40+ MB block against the oracle."""
 import importlib, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 fmrx = importlib.import_module("software-defined-radio_amd")
 from _oracle import Oracle

@@ -3,7 +3,7 @@
 PLL repairs, device time."""
 import importlib, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 fmrx = importlib.import_module("software-defined-radio_amd")
 synth = importlib.import_module("software-defined-radio_amd.synth")
