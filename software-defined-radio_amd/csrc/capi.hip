@@ -55,6 +55,7 @@ bool option_ref(Options &o, const char *name, long **as_long, int **as_int)
     else if (n == "pll_warmup") *as_int = &o.pll_warmup;
     else if (n == "pll_segment") *as_int = &o.pll_segment;
     else if (n == "pll_head") *as_int = &o.pll_head;
+    else if (n == "pll_start") *as_int = &o.pll_start;
     else if (n == "pll_align") *as_int = &o.pll_align;
     else if (n == "pll_mode") *as_int = &o.pll_mode;
     else if (n == "fused_tune") *as_int = &o.fused_tune;
@@ -76,6 +77,7 @@ Options &default_options()
         if (const char *e = std::getenv("FMRX_PLL_WARMUP")) d.pll_warmup = std::atoi(e);
         if (const char *e = std::getenv("FMRX_PLL_SEGMENT")) d.pll_segment = std::atoi(e);
         if (const char *e = std::getenv("FMRX_PLL_HEAD")) d.pll_head = std::atoi(e);
+        if (const char *e = std::getenv("FMRX_PLL_START")) d.pll_start = std::atoi(e);
         if (const char *e = std::getenv("FMRX_PLL_ALIGN")) d.pll_align = std::atoi(e);
         if (const char *e = std::getenv("FMRX_PLL_MODE")) d.pll_mode = std::atoi(e);
 #ifdef FMRX_TUNING

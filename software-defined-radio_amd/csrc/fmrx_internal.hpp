@@ -51,6 +51,8 @@ struct Options {
     int pll_warmup = -1;           // "pll_warmup" / FMRX_PLL_WARMUP: warm-up samples per lane of the parallel PLL (-1 = built-in)
     int pll_segment = -1;          // "pll_segment" / FMRX_PLL_SEGMENT: samples per lane (-1 = built-in)
     int pll_align = 0;             // "pll_align" / FMRX_PLL_ALIGN: 1 = lanes start on a multiple of the loop's period, 0 = exactly W early (default)
+    int pll_start = 1;             // "pll_start" / FMRX_PLL_START: where the parallel PLL's lanes start: 1 (default) = the state of the locked loop as a
+                                   //   linear system of the input's signs, then 64 true warm-up steps; 0 = the block's initial state plus drift, 512 steps
     int pll_head = -1;             // "pll_head" / FMRX_PLL_HEAD: samples of a stream's first call walked serially (-1 = built-in)
     int pll_mode = 0;              // "pll_mode" / FMRX_PLL_MODE: stereo PLL of the specialised pipeline: 0 = parallel in time, fast math
                                    //   (default); 1 = serial, fast math; 2 = serial, glibc math (the cause-by-cause variants of DESIGN 2)
@@ -234,6 +236,10 @@ int k_fm_pll(const float *d_in, size_t n, float *d_out, float *d_state, float fr
 // pll_parallel_scratch_floats(n) floats; d_scratch[2] (as u32) counts segments that needed a repair (diagnostic).
 // lane shape: L samples per lane, started at the last multiple of the loop's period that is >= W samples early
 constexpr int kPllSegment = 64, kPllWarmup = 512, kPllSegmentMin = 32;
+constexpr int kPllWarmupLti = 64;
+// merge tolerance on the integrator in that mode, in Ki * ulp(trigArg): lanes 64 true steps from a noise-free start still differ
+// from their neighbours by the loop's response to the float32 grid (2-3 Ki ulp), which the envelope of DESIGN section 2 contains
+constexpr float kPllIntegTolUlpsLti = 6.0f;   // true steps a lane runs in front of its segment when it starts from the linear system's state (pll_start = 1)
 constexpr int kPllHead = 1024;   // samples of a stream's first call walked serially (acquisition) before the lanes take over
 // merge tolerance between a lane's warmed-up state and the true state (see kernels_pll.hip)
 constexpr float kPllTolPhase = 1e-2f, kPllTolInteg = 1e-4f;

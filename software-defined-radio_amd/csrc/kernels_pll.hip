@@ -62,6 +62,9 @@ namespace {
 struct PllCoef {
     float Kp, Ki, ncoScale, phaseAdjust;
     double w;   // 2*PI*(freq/Fs), freq/Fs a float division as in the reference
+    float integ_tol_ulps = 2.0f;   // merge tolerance on the integrator, in Ki * ulp(trigArg)
+    // the locked loop as a linear system (pll_start = 1): Q = A^64, G = one chunk's response to the constant 1 (host: make_coef)
+    double q00 = 1.0, q01 = 0.0, q10 = 0.0, q11 = 1.0, g0 = 0.0, g1 = 0.0;
 };
 
 struct PllState {
@@ -70,6 +73,7 @@ struct PllState {
 };
 
 enum PllMath { kExact = 0, kFast = 1 };
+constexpr int kLtiChunk = 64;   // samples per chunk of the linear-system start (pll_lti_*_kernel)
 
 // One step of the recurrence.  Both forms leave the RAW trigArg in s.last: the NCO output
 // cosf(trigArg*ncoScale + phaseAdjust) is not part of the recurrence and is applied afterwards, in parallel,
@@ -187,6 +191,144 @@ __global__ void nco_out_kernel(float *__restrict__ out, size_t n, PllCoef c)
     if (k < n) out[k + 1] = nco_out<MATH>(out[k + 1], c);
 }
 
+// ---- where the lanes start, second form: the locked loop as a linear system ---------------------------------
+// The fast phase detector reads only the SIGN of its input: its output is  T - theta,  theta = trigArg / 2 pi in
+// revolutions, T the point of the lattice Z (input > 0) or Z + 1/2 (input < 0) nearest theta.  While the loop is
+// locked theta follows the pilot, so T is a staircase that climbs 1/2 at every sign change of the input: it does not
+// depend on the loop's state at all.  With  C[k] = T[k] - f * off[k]  (f = freq/Fs revolutions per sample) the
+// recurrence is linear and time-invariant in (phi, iota) = (phase, integrator) / 2 pi:
+//     iota' = iota + Ki (C - phi),   phi' = phi + Kp (C - phi) + iota'      i.e.  s' = A s + B C,
+// its memory is ~75 samples (|eig A| = 1 - 0.0133).  So the state at every 64th sample follows from the signs alone:
+//   pll_lti_chunks_kernel  one thread per 64-sample chunk: its count of sign changes and its zero-state response to
+//                          (T - T_chunk_start) - f j, j = 0..63; prefix of the counts inside a workgroup, workgroup totals;
+//   lti_start_state        (in pll_segments_kernel) T at a chunk's start from those prefixes, then
+//                          s[chunk i] = sum_{m=1..kLtiTerms} (A^64)^(m-1) R[i-m]  (+ (A^64)^i s[0] near the block start).
+// What this ignores is the float32 grid of trigArg (the true loop sees theta rounded to ulp(trigArg)): the lanes
+// therefore still run W true steps from there before their own segment.  A sign pattern that is not a locked
+// pilot's (a glitch: two sign changes within a sample or two) breaks the staircase rule; the lanes' ends then do not
+// meet their successors' starts and pll_check_nco / pll_repair walk those stretches serially, as before.
+constexpr int kLtiTerms = 20;          // (A^64)^20 ~ 5e-8: what is dropped of the state 1280 samples back
+struct LtiMat {
+    double a00, a01, a10, a11, b0, b1;   // s' = A s + B x, s = (phi, iota)
+};
+__device__ __forceinline__ LtiMat lti_of(const PllCoef &c)
+{
+    const double Kp = c.Kp, Ki = c.Ki;
+    return LtiMat{1.0 - Kp - Ki, 1.0, -Ki, 1.0, Kp + Ki, Ki};
+}
+__device__ __forceinline__ void lti_step(const LtiMat &m, double &phi, double &iota, double x)
+{
+    const double p = m.a00 * phi + m.a01 * iota + m.b0 * x;
+    iota = m.a10 * phi + m.a11 * iota + m.b1 * x;
+    phi = p;
+}
+
+// rec[4 i ..] = {R_phi, R_iota: zero-state response of chunk i to its own staircase; the climb of the chunks in front of
+// it inside its workgroup of 64 chunks; its own climb (sign changes inside it and into the next chunk's first sample, / 2)};
+// wgtot[w] = climb of workgroup w's 64 chunks.  A lane reads its chunk as 16 aligned 16-byte groups.
+__global__ __launch_bounds__(64) void pll_lti_chunks_kernel(const float *__restrict__ in, long n, PllCoef c, long nchunk,
+                                                            double *__restrict__ rec, double *__restrict__ wgtot)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const long i = static_cast<long>(blockIdx.x) * 64 + threadIdx.x;
+    const LtiMat m = lti_of(c);
+    const double f = c.w * 0.15915494309189533577;
+    double phi = 0.0, iota = 0.0, dT = 0.0;
+    if (i < nchunk) {
+        const long k0 = i * kLtiChunk;
+        const f4 *in4 = reinterpret_cast<const f4 *>(in + k0);
+        const long last4 = (n + 3) / 4 + 1 - k0 / 4;                   // groups of this chunk that are safe to read (host contract)
+        f4 v[kLtiChunk / 4];
+#pragma unroll
+        for (int q = 0; q < kLtiChunk / 4; q++) v[q] = in4[q < last4 ? q : last4];
+        const float nxt = k0 + kLtiChunk < n ? in[k0 + kLtiChunk] : 0.0f;
+        bool pos = v[0][0] > 0.0f;
+#pragma unroll
+        for (int j = 0; j < kLtiChunk; j++) {
+            lti_step(m, phi, iota, dT - f * j);
+            const long k = k0 + j + 1;
+            const float vn = j + 1 < kLtiChunk ? v[(j + 1) / 4][(j + 1) % 4] : nxt;
+            const bool pn = k < n ? vn > 0.0f : pos;
+            dT += pn != pos ? 0.5 : 0.0;
+            pos = pn;
+        }
+    }
+    // exclusive prefix of the climbs over the workgroup's 64 chunks (one wave)
+    double incl = dT;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double o = __shfl_up(incl, d, 64);
+        if (static_cast<int>(threadIdx.x) >= d) incl += o;
+    }
+    if (i < nchunk) {
+        rec[4 * i + 0] = phi;
+        rec[4 * i + 1] = iota;
+        rec[4 * i + 2] = incl - dT;
+        rec[4 * i + 3] = dT;
+    }
+    if (threadIdx.x == 63) wgtot[blockIdx.x] = incl;
+}
+
+// (integ, phase) the locked loop has in front of sample 64 i, from the chunk records: Horner over the kLtiTerms chunks
+// behind it, oldest first; near the block start the true initial state takes the place of what was dropped.  `wg_climb`
+// = climb of all chunks in front of workgroup i / 64 (the caller sums wgtot once per wave).
+struct LtiStart {
+    double q00, q01, q10, q11, g0, g1;      // Q = A^64; G = one chunk's response to the constant 1
+    double f, phi0, iota0, off0, T0;
+};
+__device__ __forceinline__ LtiStart lti_start_setup(const float *in, const float *state, const PllCoef &c)
+{
+    LtiStart L;
+    L.q00 = c.q00; L.q01 = c.q01; L.q10 = c.q10; L.q11 = c.q11; L.g0 = c.g0; L.g1 = c.g1;
+    const double inv2pi = 0.15915494309189533577;
+    L.f = c.w * inv2pi;
+    L.phi0 = static_cast<double>(state[1]) * inv2pi;
+    L.iota0 = static_cast<double>(state[0]) * inv2pi;
+    L.off0 = static_cast<double>(state[5]);
+    // the lattice point the detector sees at sample 0: nearest to theta (the float32 trigArg the state stands for)
+    const float trig0 = static_cast<float>(c.w * L.off0 + static_cast<double>(state[1]));
+    const double th0 = static_cast<double>(trig0) * inv2pi;
+    L.T0 = in[0] > 0.0f ? rint(th0) : rint(th0 - 0.5) + 0.5;
+    return L;
+}
+// wg_climb0 = climb of all chunks in front of workgroup wg0 (of 64 chunks); chunk i lies in wg0 or wg0 + 1
+__device__ __forceinline__ void lti_start_state(const LtiStart &L, const double *__restrict__ rec, const double *__restrict__ wgtot,
+                                                long i, long wg0, double wg_climb0, float &integ, float &phase)
+{
+    const double tot0 = wgtot[wg0], totm = wg0 > 0 ? wgtot[wg0 - 1] : 0.0;
+    double r0[kLtiTerms], r1[kLtiTerms];
+#pragma unroll
+    for (int t = 0; t < kLtiTerms; t++) {                     // term t: chunk j = i - (kLtiTerms - t), oldest first
+        const long jj = i - (kLtiTerms - t);
+        const long j = jj > 0 ? jj : 0;
+        const long wj = j / 64;
+        // T at the start of chunk j, from its workgroup's base (wg0 - 1, wg0 or wg0 + 1) and its prefix inside it
+        const double wbase = wj == wg0 ? wg_climb0 : (wj > wg0 ? wg_climb0 + tot0 : wg_climb0 - totm);
+        const double base = (L.T0 + wbase + rec[4 * j + 2]) - L.f * (L.off0 + static_cast<double>(j * kLtiChunk)) - L.phi0;
+        r0[t] = rec[4 * j + 0] + base * L.g0;
+        r1[t] = rec[4 * j + 1] + base * L.g1;
+    }
+    double p = 0.0, q = 0.0;
+#pragma unroll
+    for (int t = 0; t < kLtiTerms; t++) {
+        const long jj = i - (kLtiTerms - t);
+        if (jj == 0) {                                        // the block's true initial state, in deviations from (phi0, 0)
+            p = 0.0;
+            q = L.iota0;
+        }
+        const double np = L.q00 * p + L.q01 * q + r0[t];
+        const double nq = L.q10 * p + L.q11 * q + r1[t];
+        p = jj >= 0 ? np : p;
+        q = jj >= 0 ? nq : q;
+    }
+    if (i == 0) {
+        p = 0.0;
+        q = L.iota0;
+    }
+    integ = static_cast<float>(q * 6.28318530717958647692);
+    phase = static_cast<float>((L.phi0 + p) * 6.28318530717958647692);
+}
+
 // ---- parallel in time -------------------------------------------------------------------------
 // seg[s*16 + 0..5]  state at the END of segment s      (after sample a_s + L - 1; fbI/fbQ/last finished)
 // seg[s*16 + 8..9]  (integ, phase) this lane had at the START of segment s (after its warm-up)
@@ -201,9 +343,24 @@ __global__ void nco_out_kernel(float *__restrict__ out, size_t n, PllCoef c)
 // samples instead of the 768 it takes to forget a guess that ignores the ripple).  P = 0: no alignment.
 __global__ void pll_segments_kernel(const float *__restrict__ in, long n, float *__restrict__ out,
                                     const float *__restrict__ state, PllCoef c, int L, int W, int P, long nseg,
-                                    float *__restrict__ seg, float *hdr)
+                                    float *__restrict__ seg, float *hdr, const double *__restrict__ lti_rec,
+                                    const double *__restrict__ lti_wgtot)
 {
     const long sg = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    // linear-system start: the climb of the chunk workgroups in front of the one this wave's first lane starts in, summed by
+    // the whole wave (its 64 lanes start in that workgroup of 64 chunks or the next one)
+    long lti_wg0 = 0;
+    double lti_climb0 = 0.0;
+    if (lti_rec) {
+        const long a0 = static_cast<long>(blockIdx.x) * blockDim.x * L;
+        const long k0 = a0 > W ? a0 - W : 0;
+        lti_wg0 = (k0 / kLtiChunk) / 64;
+        double part = 0.0;
+        for (long u = threadIdx.x; u < lti_wg0; u += 64) part += lti_wgtot[u];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+        lti_climb0 = part;
+    }
     if (sg >= nseg) return;
     const long a = sg * L;
     const long b = a + L < n ? a + L : n;
@@ -215,9 +372,15 @@ __global__ void pll_segments_kernel(const float *__restrict__ in, long n, float 
         if (P > 0) k -= k % P;
     }
     if (k > 0) {
-        // hdr[5..7] = {phase at the start of the previous call, its length, valid}: the drift
-        const float slope = hdr[7] != 0.0f ? (s0.phase - hdr[5]) / hdr[6] : 0.0f;
-        s.phase = s0.phase + slope * static_cast<float>(k);
+        if (lti_rec) {
+            // the linear system's state in front of sample k (a multiple of 64: host contract)
+            const LtiStart Ls = lti_start_setup(in, state, c);
+            lti_start_state(Ls, lti_rec, lti_wgtot, k / kLtiChunk, lti_wg0, lti_climb0, s.integ, s.phase);
+        } else {
+            // hdr[5..7] = {phase at the start of the previous call, its length, valid}: the drift
+            const float slope = hdr[7] != 0.0f ? (s0.phase - hdr[5]) / hdr[6] : 0.0f;
+            s.phase = s0.phase + slope * static_cast<float>(k);
+        }
         s.off = s0.off + static_cast<float>(k);
         const float trigArg = static_cast<float>(c.w * static_cast<double>(s.off) + static_cast<double>(s.phase));
         const double rev = static_cast<double>(trigArg) * 0.15915494309189533577;
@@ -296,6 +459,13 @@ __device__ __forceinline__ float pll_trig_ulp(const float *state, long n, const 
     const float top = static_cast<float>(c.w * (static_cast<double>(state[5]) + static_cast<double>(n)));
     return __uint_as_float((__float_as_uint(top) & 0x7f800000u)) * 1.1920929e-7f;   // 2^(e-23)
 }
+// Two phase estimates that differ by whole turns stand for the same loop state (trigArg only enters through sin / cos and the
+// NCO's cos): a lane that counted one pilot cycle more or less than its neighbour is not wrong.  |a - b| modulo 2 pi.
+__device__ __forceinline__ float pll_phase_dist(float a, float b)
+{
+    const float d = a - b;
+    return fabsf(d - 6.28318530717958647692f * rintf(d * 0.15915494309189533577f));
+}
 __device__ __forceinline__ float pll_phase_tol(float base, const float *state, long n, const PllCoef &c)
 {
     return base + 2.0f * pll_trig_ulp(state, n, c);
@@ -304,7 +474,7 @@ __device__ __forceinline__ float pll_phase_tol(float base, const float *state, l
 // grid: two trajectories cannot agree better than a couple of such steps
 __device__ __forceinline__ float pll_integ_tol(float base, const float *state, long n, const PllCoef &c)
 {
-    return base + 2.0f * c.Ki * pll_trig_ulp(state, n, c);
+    return base + c.integ_tol_ulps * c.Ki * pll_trig_ulp(state, n, c);
 }
 
 // Judge and finish.  One workgroup per 256 segments: (1) mark every segment whose start state differs from its
@@ -327,7 +497,7 @@ __global__ __launch_bounds__(kCheckThreads) void pll_check_nco_kernel(
         float dp = 0.0f, di = 0.0f;
         if (sg >= 1 && sg < nseg) {
             di = fabsf(seg[sg * 16 + 8] - seg[(sg - 1) * 16 + 0]);
-            dp = fabsf(seg[sg * 16 + 9] - seg[(sg - 1) * 16 + 1]);
+            dp = pll_phase_dist(seg[sg * 16 + 9], seg[(sg - 1) * 16 + 1]);
             bad = !(dp <= tol_phase && di <= tol_integ);
             if (bad) dp = di = 0.0f;
         }
@@ -410,7 +580,7 @@ __global__ __launch_bounds__(kRepairThreads) void pll_repair_kernel(
             repaired++;
             atomicAnd(badmask + sg / 64, ~(1ull << (sg % 64)));
             if (sg + 1 < nseg) {
-                const bool merged = fabsf(seg[(sg + 1) * 16 + 9] - s.phase) <= tol_phase &&
+                const bool merged = pll_phase_dist(seg[(sg + 1) * 16 + 9], s.phase) <= tol_phase &&
                                     fabsf(seg[(sg + 1) * 16 + 8] - s.integ) <= tol_integ;
                 const bool was_bad = is_bad(sg + 1);
                 if (merged) {
@@ -455,6 +625,15 @@ PllCoef make_coef(float freq, float Fs, float ncoScale, float phaseAdjust, float
     c.ncoScale = ncoScale;
     c.phaseAdjust = phaseAdjust;
     c.w = 2 * 3.14159265358979323846 * static_cast<double>(freq / Fs);
+    // s' = A s + B x in (phase, integrator) / 2 pi: Q = A^64 and the response G of 64 steps to x = 1 (pll_lti_chunks_kernel)
+    const double Kp = c.Kp, Ki = c.Ki, a00 = 1.0 - Kp - Ki, a01 = 1.0, a10 = -Ki, a11 = 1.0, b0 = Kp + Ki, b1 = Ki;
+    for (int j = 0; j < kLtiChunk; j++) {
+        const double g0 = a00 * c.g0 + a01 * c.g1 + b0, g1 = a10 * c.g0 + a11 * c.g1 + b1;
+        c.g0 = g0; c.g1 = g1;
+        const double n00 = a00 * c.q00 + a01 * c.q10, n01 = a00 * c.q01 + a01 * c.q11;
+        const double n10 = a10 * c.q00 + a11 * c.q10, n11 = a10 * c.q01 + a11 * c.q11;
+        c.q00 = n00; c.q01 = n01; c.q10 = n10; c.q11 = n11;
+    }
     return c;
 }
 
@@ -495,7 +674,8 @@ int k_libm_eval(int fn, const float *d_a, const float *d_b, size_t n, float *d_o
 size_t pll_parallel_scratch_floats(size_t n)
 {
     const size_t nseg = n / kPllSegmentMin + 2;
-    return 8 + nseg * 16 + 2 * (nseg / 64 + 2);
+    const size_t nchunk = n / kLtiChunk + 2;
+    return 8 + nseg * 16 + 2 * (nseg / 64 + 2) + 2 + (nchunk + 2) * 8 + 2 * (nchunk / 64 + 2);   // + chunk records (4 doubles), workgroup totals
 }
 
 int k_fm_pll_parallel(const float *d_in, size_t n, float *d_out, float *d_state, float freq, float Fs, float ncoScale,
@@ -504,14 +684,20 @@ int k_fm_pll_parallel(const float *d_in, size_t n, float *d_out, float *d_state,
     int L = kPllSegment, W = kPllWarmup;
     if (o.pll_warmup >= 0 && o.pll_warmup <= 65536) W = o.pll_warmup / 4 * 4;                    // tuning: warm-up samples per lane
     if (o.pll_segment >= kPllSegmentMin && o.pll_segment <= 65536) L = o.pll_segment / 4 * 4;   // tuning: samples per lane
+    if (o.pll_start == 1) {
+        // lanes start from the linear system's state (see pll_lti_chunks_kernel): W, L in whole 64-sample chunks
+        if (o.pll_warmup < 0) W = kPllWarmupLti;
+        W = (W + kLtiChunk - 1) / kLtiChunk * kLtiChunk;
+        L = kLtiChunk;                                             // one lane per chunk (a wave's 64 lanes then start inside two chunk workgroups)
+    }
     if (reinterpret_cast<uintptr_t>(d_in) % 16)
         return fail(FMRX_EINVAL, "fm_pll_parallel: input must be 16-byte aligned (the lanes fetch 16-byte groups)");
     if (n < static_cast<size_t>(4 * L))   // nothing to gain
         return k_fm_pll(d_in, n, d_out, d_state, freq, Fs, ncoScale, phaseAdjust, normBandwidth, 1, s);
-    const PllCoef c = make_coef(freq, Fs, ncoScale, phaseAdjust, normBandwidth);
+    PllCoef c = make_coef(freq, Fs, ncoScale, phaseAdjust, normBandwidth);
     // the loop's state repeats every P samples on an on-frequency pilot: Fs / gcd(Fs, freq), when both are whole Hz
     int P = 0;
-    if (o.pll_align != 0 && Fs == static_cast<float>(static_cast<long>(Fs)) && freq == static_cast<float>(static_cast<long>(freq)) && freq > 0) {
+    if (o.pll_align != 0 && o.pll_start != 1 && Fs == static_cast<float>(static_cast<long>(Fs)) && freq == static_cast<float>(static_cast<long>(freq)) && freq > 0) {
         long x = static_cast<long>(Fs), y = static_cast<long>(freq);
         while (y) { const long t = x % y; x = y; y = t; }
         const long p = static_cast<long>(Fs) / x;
@@ -524,8 +710,23 @@ int k_fm_pll_parallel(const float *d_in, size_t n, float *d_out, float *d_state,
     float *seg = d_scratch + 8;
     unsigned long long *badmask = reinterpret_cast<unsigned long long *>(seg + (nseg + 1) * 16);
     const unsigned grid = static_cast<unsigned>((nseg + 63) / 64);
+    const double *lti_rec = nullptr, *lti_wgtot = nullptr;
+    if (o.pll_start == 1) {
+        c.integ_tol_ulps = kPllIntegTolUlpsLti;
+        const long nchunk = static_cast<long>(n / kLtiChunk) + 1;
+        const size_t mask_floats = 2 * (static_cast<size_t>(nseg) / 64 + 2);
+        size_t off = 8 + (static_cast<size_t>(nseg) + 1) * 16 + mask_floats;
+        off += off & 1;                                            // doubles
+        double *rec = reinterpret_cast<double *>(d_scratch + off);
+        double *wgtot = rec + 4 * (nchunk + 1);
+        hipLaunchKernelGGL(pll_lti_chunks_kernel, dim3(static_cast<unsigned>((nchunk + 63) / 64)), dim3(64), 0, s, d_in,
+                           static_cast<long>(n), c, nchunk, rec, wgtot);
+        FMRX_LAUNCH_CHECK("pll_lti_chunks");
+        lti_rec = rec;
+        lti_wgtot = wgtot;
+    }
     hipLaunchKernelGGL(pll_segments_kernel, dim3(grid), dim3(64), 0, s, d_in, static_cast<long>(n), d_out, d_state, c, L, W, P,
-                       nseg, seg, d_scratch);
+                       nseg, seg, d_scratch, lti_rec, lti_wgtot);
     FMRX_LAUNCH_CHECK("pll_segments");
     hipLaunchKernelGGL(pll_check_nco_kernel, dim3(static_cast<unsigned>((nseg + kCheckSegs - 1) / kCheckSegs)), dim3(kCheckThreads), 0, s,
                        seg, nseg, badmask, kPllTolPhase, kPllTolInteg, reinterpret_cast<unsigned *>(d_scratch), d_state,

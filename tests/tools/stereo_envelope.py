@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Stereo error vs stream time, cause by cause: the same 2.13 s mode-0 stereo stream
 through the GPU pipeline in four configurations, each against the oracle (= the compiled reference, bit for
-bit) for the whole stream, RMS error of the left channel per 0.1 s window, in absolute terms and in units of
+bit) for the whole stream, RMS error of the left channel per {win / 48000.0:.1f} s window, in absolute terms and in units of
 ulp(trigArg(t)):
    fast / parallel   default: specialised kernels, parallel-in-time PLL, fast math (closed-form phase detector)
    fast / serial     pll_mode 1: same math, serial recurrence               -> isolates the segment merge
@@ -35,12 +35,18 @@ def main():
     iq = o.synth_fm_u8(p.block_bytes // 2 * nblk, rf_Fs=p.rf_Fs, seed=0x3D74)
     po = o.pipeline(0, 2)
     Lo = np.concatenate([po.process(iq[k:k + p.block_bytes])["audio_l"] for k in range(0, len(iq), p.block_bytes)])
-    win = 4800
-    t_end = (np.arange(len(Lo) // win) + 1) * 0.1
+    win = 4800 if nblk <= 200 else 48000          # 0.1 s windows (1 s for long streams)
+    t_end = (np.arange(len(Lo) // win) + 1) * (win / 48000.0)
     rows = {}
-    for name, cfg in (("fast/parallel", {}), ("fast/serial", {"pll_mode": 1}), ("fast/glibc", {"pll_mode": 2}),
-                      ("par W512 L64", {"pll_warmup": 512, "pll_segment": 64}), ("par W384 L64", {"pll_warmup": 384, "pll_segment": 64}),
-                      ("par W256 L64", {"pll_warmup": 256, "pll_segment": 64}), ("bit-exact", {"generic": 1})):
+    diag = {}
+    sets = {"default": (("fast/parallel", {}), ("fast/serial", {"pll_mode": 1}), ("fast/glibc", {"pll_mode": 2}),
+                        ("par W512 L64", {"pll_warmup": 512, "pll_segment": 64}), ("par W384 L64", {"pll_warmup": 384, "pll_segment": 64}),
+                        ("par W256 L64", {"pll_warmup": 256, "pll_segment": 64}), ("bit-exact", {"generic": 1})),
+            # lanes started from the locked loop as a linear system of the input's signs (pll_start = 1), by warm-up length
+            "lti": (("start 0 W512", {"pll_start": 0}), ("lti W0", {"pll_start": 1, "pll_warmup": 0}), ("lti W64", {"pll_start": 1, "pll_warmup": 64}),
+                    ("lti W128", {"pll_start": 1, "pll_warmup": 128}), ("lti W256", {"pll_start": 1, "pll_warmup": 256}),
+                    ("fast/serial", {"pll_mode": 1}))}
+    for name, cfg in sets[sys.argv[3] if len(sys.argv) > 3 else "default"]:
         pl = fmrx.Pipeline(0, 2, max_block_bytes=bb)
         for k, v in cfg.items():
             if k == "generic":
@@ -50,15 +56,17 @@ def main():
         t0 = time.perf_counter()
         L = np.concatenate([pl.process(iq[k:k + bb])["audio_l"] for k in range(0, len(iq) // bb * bb, bb)])
         dt = time.perf_counter() - t0
+        diag[name] = pl.pll_diagnostics() if hasattr(pl, "pll_diagnostics") else None
         n = min(len(L), len(Lo)) // win * win
         d = (L[:n].astype(np.float64) - Lo[:n]).reshape(-1, win)
         rows[name] = (np.sqrt(np.mean(d * d, axis=1)), dt)
     names = list(rows)
     print(f"# mode 0 stereo, {nblk} reference blocks = {nblk * 51200 / 2.4e6:.2f} s, fed as {bb}-byte blocks; "
-          f"left-channel RMS error vs the oracle per 0.1 s window: absolute (in ulp(trigArg))")
+          f"left-channel RMS error vs the oracle per {win / 48000.0:.1f} s window: absolute (in ulp(trigArg))")
     print("t_end[s]  ulp(trigArg)  " + "  ".join(f"{n:>22s}" for n in names))
     for i, t in enumerate(t_end[: len(rows[names[0]][0])]):
         print(f"{t:7.1f}  {ulp(t):11.2e}  " + "  ".join(f"{rows[n][0][i]:12.2e} ({rows[n][0][i] / ulp(t):5.3f})" for n in names))
+    print("repaired segments / largest accepted |dphase|, |dinteg| of the last call: " + ", ".join(f"{n} {diag[n]}" for n in names))
     print("wall seconds incl. host copies: " + ", ".join(f"{n} {rows[n][1]:.2f}" for n in names))
 
 

@@ -13,10 +13,11 @@ bb = 2048000
 iq = torch.from_numpy(synth.synth_fm_u8(3 * bb // 2, 2.4e6, seed=0x3D74)).cuda().repeat(blocks // 3)
 nb = iq.numel()
 s = torch.cuda.current_stream().cuda_stream
-cfgs = [(768, 64, 0), (768, 32, 0), (768, 128, 0), (768, 512, 0), (512, 64, 0), (512, 64, 1), (384, 64, 1), (256, 64, 1), (1024, 64, 0)]
-for W, L, A in cfgs:
+# (warm-up, segment, align, start): start 1 = lanes start from the locked loop as a linear system of the input's signs
+cfgs = [(512, 64, 0, 0), (768, 64, 0, 0), (256, 64, 1, 0), (0, 64, 0, 1), (64, 64, 0, 1), (128, 64, 0, 1), (64, 128, 0, 1), (256, 64, 0, 1)]
+for W, L, A, S in cfgs:
     pl = fmrx.Pipeline(0, 2, max_block_bytes=nb)
-    for k, v in (("pll_warmup", W), ("pll_segment", L), ("pll_align", A)):
+    for k, v in (("pll_warmup", W), ("pll_segment", L), ("pll_align", A), ("pll_start", S)):
         pl.set_option(k, v)
     na = pl.n_audio(nb)
     d_pcm = torch.empty(2 * na, dtype=torch.int16, device="cuda")
@@ -31,6 +32,6 @@ for W, L, A in cfgs:
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 4
     rep, dp, di = pl.pll_diagnostics()
-    print(f"W={W:4d} L={L:4d} align={A}: {ms*1e3:8.1f} us per {nb//2} samples = {nb/2/ms/1e3:9.0f} MS/s = {2.08*nb/2/ms/1e6/8000:.4f} of HBM peak; "
+    print(f"W={W:4d} L={L:4d} align={A} start={S}: {ms*1e3:8.1f} us per {nb//2} samples = {nb/2/ms/1e3:9.0f} MS/s = {2.08*nb/2/ms/1e6/8000:.4f} of HBM peak; "
           f"repaired segments {rep}, max accepted dphase {dp:.2e} dinteg {di:.2e}", flush=True)
     pl.close()
