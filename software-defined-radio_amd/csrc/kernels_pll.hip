@@ -38,15 +38,21 @@
 //     closed form (atan2f(v*-sin t, v*cos t) = -t, turned by pi for v < 0).
 //  2. Parallel in time.  A locked loop forgets its past (contraction |1 - Kp| per
 //     step, damping 0.707) down to the trigArg grid.  The block is cut into segments
-//     of L samples, one lane each; a lane starts W samples early from the block's
-//     initial state (phase extrapolated with the slope observed over the previous
-//     block) and runs the same recurrence; after the warm-up it agrees with the serial
-//     trajectory TO WITHIN THE GRID, not bit for bit.  A second kernel compares, for
-//     every segment, the state a lane had at its segment start with the state its
-//     predecessor ended on, against a tolerance (kPllTolPhase + 2 ulp(trigArg) on the
-//     phase, kPllTolInteg + 2 Ki ulp(trigArg) on the integrator); a third walks the
+//     of L = 64 samples, one lane each; a lane starts W samples early from an estimate
+//     of the loop's state there and runs the same recurrence; after the warm-up it
+//     agrees with the serial trajectory TO WITHIN THE GRID, not bit for bit.  The
+//     estimate (option pll_start): 1 (default) -- the closed-form phase detector reads
+//     only the SIGN of the input, so the locked loop is a linear time-invariant system
+//     driven by a staircase that climbs half a turn per sign change: its state at
+//     every 64th sample follows from the signs alone (pll_lti_chunks_kernel +
+//     lti_start_state below), W = 64 true steps then put the lane on the float32 grid;
+//     0 -- the block's initial state with the phase drift of the previous block,
+//     W = 512.  A second kernel compares, for every segment, the state a lane had at
+//     its segment start with the state its predecessor ended on, against a tolerance
+//     (kPllTolPhase + 2 ulp(trigArg) on the phase, modulo whole turns; kPllTolInteg +
+//     2 or 6 Ki ulp(trigArg) on the integrator); a third walks the
 //     recurrence serially from every segment that is outside it (loop not locked:
-//     stream start, drop-outs, phase jumps) until it is inside again.
+//     stream start, drop-outs, phase jumps, no pilot) until it is inside again.
 //    What FAST guarantees is therefore the error floor described above, not identity:
 //    tests/test_gpu_parity.py::test_stereo_error_envelope_long_stream states and checks
 //    the envelope against the oracle.
@@ -426,7 +432,7 @@ __global__ void pll_segments_kernel(const float *__restrict__ in, long n, float 
         q0 = q1;
         q1 = q2;
         q2 = grp(++g + 2);
-        float r0, r1, r2, r3;                              // raw trigArg: pll_check_nco_kernel applies the NCO
+        float r0, r1, r2, r3;                              // raw trigArg of the four steps
         if (__builtin_expect(__any(!(pll_ordinary(cur.x) && pll_ordinary(cur.y) && pll_ordinary(cur.z) && pll_ordinary(cur.w))), 0)) {
             pll_step<kFast>(s, cur.x, c); r0 = s.last;
             pll_step<kFast>(s, cur.y, c); r1 = s.last;
@@ -438,14 +444,15 @@ __global__ void pll_segments_kernel(const float *__restrict__ in, long n, float 
             pll_step_clean(s, cur.z, c); r2 = s.last;
             pll_step_clean(s, cur.w, c); r3 = s.last;
         }
-        out[k + 1] = r0;
-        out[k + 2] = r1;
-        out[k + 3] = r2;
-        out[k + 4] = r3;
+        // finished NCO values (off the recurrence's dependency chain: the lane's issue slots are mostly idle)
+        out[k + 1] = nco_out<kFast>(r0, c);
+        out[k + 2] = nco_out<kFast>(r1, c);
+        out[k + 3] = nco_out<kFast>(r2, c);
+        out[k + 4] = nco_out<kFast>(r3, c);
     }
     for (int i = 0; k < b; k++, i++) {                    // the block's ragged end (last segment only)
         pll_step<kFast>(s, q0[i], c);
-        out[k + 1] = s.last;
+        out[k + 1] = nco_out<kFast>(s.last, c);
     }
     finish_state<kFast>(s, c);
     store_state(seg + sg * 16, s);
@@ -477,77 +484,52 @@ __device__ __forceinline__ float pll_integ_tol(float base, const float *state, l
     return base + c.integ_tol_ulps * c.Ki * pll_trig_ulp(state, n, c);
 }
 
-// Judge and finish.  One workgroup per 256 segments: (1) mark every segment whose start state differs from its
-// predecessor's end state by more than the merge tolerance (the mask words are written whole: no memset, no
-// atomics) and record the largest differences among the accepted ones (diagnostics); (2) apply the NCO,
-// out[k+1] = cos(trigArg*ncoScale + phaseAdjust), in place to the workgroup's stretch of the output, leaving
-// out the segments just marked: pll_repair_kernel walks those again and writes finished values itself.
-constexpr int kCheckThreads = 256, kCheckSegs = 64;
-__global__ __launch_bounds__(kCheckThreads) void pll_check_nco_kernel(
-    const float *__restrict__ seg, long nseg, unsigned long long *__restrict__ badmask, float tol_phase_base, float tol_integ,
-    unsigned *__restrict__ diag, const float *__restrict__ state, long n, PllCoef c, int L, float *__restrict__ out)
+// Judge.  Every thread judges one segment: its lane's start state against its predecessor's end state, to the merge
+// tolerance (the mask words are written whole: no memset); the largest accepted differences are kept for diagnostics.
+// (Judge and finish in ONE launch -- the last workgroup to take a ticket doing the rest -- was measured: the device-scope
+// fences it needs cost more than the second launch, 10.2 vs 7 us.)
+constexpr int kCheckThreads = 256;
+__global__ __launch_bounds__(kCheckThreads) void pll_check_kernel(
+    const float *__restrict__ seg, long nseg, unsigned long long *__restrict__ badmask, float tol_phase_base, float tol_integ_base,
+    unsigned *__restrict__ diag, const float *__restrict__ state, long n, PllCoef c)
 {
-    __shared__ unsigned long long word;
-    const long s0 = static_cast<long>(blockIdx.x) * kCheckSegs;
-    if (threadIdx.x < kCheckSegs) {                        // wave 0 judges the workgroup's 64 segments
-        const long sg = s0 + threadIdx.x;
-        const float tol_phase = pll_phase_tol(tol_phase_base, state, n, c);
-        tol_integ = pll_integ_tol(tol_integ, state, n, c);
-        bool bad = false;
-        float dp = 0.0f, di = 0.0f;
-        if (sg >= 1 && sg < nseg) {
-            di = fabsf(seg[sg * 16 + 8] - seg[(sg - 1) * 16 + 0]);
-            dp = pll_phase_dist(seg[sg * 16 + 9], seg[(sg - 1) * 16 + 1]);
-            bad = !(dp <= tol_phase && di <= tol_integ);
-            if (bad) dp = di = 0.0f;
-        }
-        const unsigned long long m = __ballot(bad);
-        for (int o = 32; o; o >>= 1) {
-            dp = fmaxf(dp, __shfl_xor(dp, o, 64));
-            di = fmaxf(di, __shfl_xor(di, o, 64));
-        }
-        if (threadIdx.x == 0) {
-            word = m;
-            badmask[s0 / 64] = m;
-            if (m) reinterpret_cast<float *>(diag)[1] = 1.0f;          // every writer writes the same value
-            // diagnostics: largest accepted differences.  Read before the atomic: 300 workgroups hammering two addresses
-            // cost more than the rest of the kernel; after the first few the maximum rarely moves
-            if (__float_as_uint(dp) > diag[3]) atomicMax(diag + 3, __float_as_uint(dp));   // non-negative floats order like their bit patterns
-            if (__float_as_uint(di) > diag[4]) atomicMax(diag + 4, __float_as_uint(di));
-        }
+    const float tol_phase = pll_phase_tol(tol_phase_base, state, n, c);
+    const float tol_integ = pll_integ_tol(tol_integ_base, state, n, c);
+    const long sg = static_cast<long>(blockIdx.x) * kCheckThreads + threadIdx.x;
+    bool bad = false;
+    float dp = 0.0f, di = 0.0f;
+    if (sg >= 1 && sg < nseg) {
+        di = fabsf(seg[sg * 16 + 8] - seg[(sg - 1) * 16 + 0]);
+        dp = pll_phase_dist(seg[sg * 16 + 9], seg[(sg - 1) * 16 + 1]);
+        bad = !(dp <= tol_phase && di <= tol_integ);
+        if (bad) dp = di = 0.0f;
     }
-    __syncthreads();
-    // the workgroup's stretch of the output in groups of 4 samples (L is a multiple of 4: a group lies in one segment)
-    const unsigned long long w = word;
-    const long k0 = s0 * L;
-    const long k1 = (s0 + kCheckSegs) * L < n ? (s0 + kCheckSegs) * L : n;
-    const float inv_lq = 4.0f / static_cast<float>(L);
-    for (long g = threadIdx.x; k0 + 4 * g < k1; g += kCheckThreads) {
-        const int ls = static_cast<int>((static_cast<float>(g) + 0.5f) * inv_lq);   // g / (L/4): exact for g < 2^20
-        if ((w >> ls) & 1ull) continue;
-        const long k = k0 + 4 * g;
-#pragma unroll
-        for (int e = 0; e < 4; e++)
-            if (k + e < k1) out[k + e + 1] = nco_out<kFast>(out[k + e + 1], c);
+    const unsigned long long m = __ballot(bad);
+    for (int o = 32; o; o >>= 1) {
+        dp = fmaxf(dp, __shfl_xor(dp, o, 64));
+        di = fmaxf(di, __shfl_xor(di, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0 && sg / 64 <= (nseg - 1) / 64) {
+        badmask[sg / 64] = m;
+        if (m) reinterpret_cast<float *>(diag)[1] = 1.0f;          // every writer writes the same value
+        // read before the atomic: hundreds of waves hammering two addresses cost more than the rest of the kernel
+        if (__float_as_uint(dp) > diag[3]) atomicMax(diag + 3, __float_as_uint(dp));   // non-negative floats order like their bit patterns
+        if (__float_as_uint(di) > diag[4]) atomicMax(diag + 4, __float_as_uint(di));
     }
 }
 
-// Repair (a no-op when every segment merged).  A mismatching segment whose predecessor is valid is
-// walked again from the predecessor's (true) end state; then its successor is judged again against
-// the new end state.  Mismatching segments that are not neighbours do not depend on each other, so
-// every round repairs all of them at once, one lane each, and a run of r consecutive bad segments
-// takes r rounds: typically one or two rounds of one segment's time instead of one lane walking all
-// of them in turn.  The result is the serial recurrence's, whatever the order.  Then publish the
-// block's end state.
-constexpr int kRepairThreads = 1024;
+// Finish (one workgroup): walk every flagged segment again from its predecessor's true end state, round by round, until
+// the successors merge (usually there is nothing to do: a locked pilot flags no segment), and store the block's end
+// state.  The segments' outputs are finished NCO values already; a repaired segment's are rewritten.
+constexpr int kRepairThreads = 256;
 __global__ __launch_bounds__(kRepairThreads) void pll_repair_kernel(
     const float *__restrict__ in, long n, float *__restrict__ out, float *__restrict__ state, PllCoef c, int L, long nseg,
-    float *__restrict__ seg, unsigned long long *__restrict__ badmask, float tol_phase_base, float tol_integ,
+    float *__restrict__ seg, unsigned long long *__restrict__ badmask, float tol_phase_base, float tol_integ_base,
     unsigned *__restrict__ n_repaired, float *__restrict__ hdr)
 {
     __shared__ int any_todo;
     const float tol_phase = pll_phase_tol(tol_phase_base, state, n, c);
-    tol_integ = pll_integ_tol(tol_integ, state, n, c);
+    const float tol_integ = pll_integ_tol(tol_integ_base, state, n, c);
     auto is_bad = [&](long sg) { return (badmask[sg / 64] >> (sg % 64)) & 1ull; };
     unsigned repaired = 0;
     const bool nothing_to_do = hdr[1] == 0.0f;             // the common case: every segment merged
@@ -556,7 +538,7 @@ __global__ __launch_bounds__(kRepairThreads) void pll_repair_kernel(
         __syncthreads();
         // this round's work is fixed before anything changes: bad segments with a valid predecessor
         // (their successors are then not in the round, so a lane's updates touch nobody else's input)
-        constexpr int kMaxPer = 8;                     // segments per lane and round (nseg <= 8192 per round; more: next round)
+        constexpr int kMaxPer = 8;                     // segments per lane and round; more: next round
         long todo[kMaxPer];
         int nt = 0;
         for (long sg = 1 + threadIdx.x; sg < nseg && nt < kMaxPer; sg += kRepairThreads)
@@ -573,25 +555,18 @@ __global__ __launch_bounds__(kRepairThreads) void pll_repair_kernel(
                 const float v = vn;
                 vn = in[k + 1 < b ? k + 1 : k];
                 pll_step<kFast>(s, v, c);
-                out[k + 1] = nco_out<kFast>(s.last, c);     // finished values: pll_check_nco_kernel left this segment out
+                out[k + 1] = nco_out<kFast>(s.last, c);
             }
             finish_state<kFast>(s, c);
             store_state(seg + sg * 16, s);
             repaired++;
             atomicAnd(badmask + sg / 64, ~(1ull << (sg % 64)));
             if (sg + 1 < nseg) {
+                // does the successor's lane stand on the repaired state?  (its outputs are finished values either way)
                 const bool merged = pll_phase_dist(seg[(sg + 1) * 16 + 9], s.phase) <= tol_phase &&
                                     fabsf(seg[(sg + 1) * 16 + 8] - s.integ) <= tol_integ;
-                const bool was_bad = is_bad(sg + 1);
-                if (merged) {
-                    atomicAnd(badmask + (sg + 1) / 64, ~(1ull << ((sg + 1) % 64)));
-                    if (was_bad) {   // its lane's trajectory stands after all, but its outputs are still raw trigArg
-                        const long a2 = (sg + 1) * L, b2 = a2 + L < n ? a2 + L : n;
-                        for (long k = a2; k < b2; k++) out[k + 1] = nco_out<kFast>(out[k + 1], c);
-                    }
-                } else {
-                    atomicOr(badmask + (sg + 1) / 64, 1ull << ((sg + 1) % 64));
-                }
+                if (merged) atomicAnd(badmask + (sg + 1) / 64, ~(1ull << ((sg + 1) % 64)));
+                else atomicOr(badmask + (sg + 1) / 64, 1ull << ((sg + 1) % 64));
             }
         }
         __threadfence();
@@ -599,7 +574,7 @@ __global__ __launch_bounds__(kRepairThreads) void pll_repair_kernel(
     }
     if (n_repaired && repaired) atomicAdd(n_repaired, repaired);
     if (threadIdx.x == 0) {
-        // remember where this call's phase started, for the next call's extrapolation
+        // remember where this call's phase started, for the next call's extrapolation (pll_start = 0)
         hdr[5] = state[1];
         hdr[6] = static_cast<float>(n);
         hdr[7] = 1.0f;
@@ -728,10 +703,9 @@ int k_fm_pll_parallel(const float *d_in, size_t n, float *d_out, float *d_state,
     hipLaunchKernelGGL(pll_segments_kernel, dim3(grid), dim3(64), 0, s, d_in, static_cast<long>(n), d_out, d_state, c, L, W, P,
                        nseg, seg, d_scratch, lti_rec, lti_wgtot);
     FMRX_LAUNCH_CHECK("pll_segments");
-    hipLaunchKernelGGL(pll_check_nco_kernel, dim3(static_cast<unsigned>((nseg + kCheckSegs - 1) / kCheckSegs)), dim3(kCheckThreads), 0, s,
-                       seg, nseg, badmask, kPllTolPhase, kPllTolInteg, reinterpret_cast<unsigned *>(d_scratch), d_state,
-                       static_cast<long>(n), c, L, d_out);
-    FMRX_LAUNCH_CHECK("pll_check_nco");
+    hipLaunchKernelGGL(pll_check_kernel, dim3(static_cast<unsigned>((nseg + kCheckThreads - 1) / kCheckThreads)), dim3(kCheckThreads), 0, s,
+                       seg, nseg, badmask, kPllTolPhase, kPllTolInteg, reinterpret_cast<unsigned *>(d_scratch), d_state, static_cast<long>(n), c);
+    FMRX_LAUNCH_CHECK("pll_check");
     hipLaunchKernelGGL(pll_repair_kernel, dim3(1), dim3(kRepairThreads), 0, s, d_in, static_cast<long>(n), d_out, d_state, c, L, nseg, seg,
                        badmask, kPllTolPhase, kPllTolInteg, n_repaired, d_scratch);
     FMRX_LAUNCH_CHECK("pll_repair");
