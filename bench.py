@@ -305,10 +305,13 @@ def side_legs(torch, fmrx, synth, args, pl, step, d_iq, n_bytes, stream) -> dict
         d_pcm = torch.empty(channels * na, dtype=torch.int16, device="cuda")
         fn = lambda: q.process_dev(d_in.data_ptr(), nb, None, d_pcm.data_ptr(), wrap=True, stream=stream)
         if channels == 2:
-            # the reference's float32 trigOffset stops counting at 2^24 IF samples (70 s of stream): keep the whole
-            # measurement (2 + 8 steps of 1.23 M IF samples) a fresh stream below that
+            # the reference's float32 trigArg is down to a resolution of 0.5 rad 8.4 M IF samples (35 s) into a stream, where the PLL
+            # lanes fall back to long warm-ups, and its trigOffset stops counting at 2^24 (70 s): the whole
+            # measurement (warm-up + timed steps) is a fresh stream's first 31 s
             q.reset()
-            ms = event_ms(torch, fn, 8, warm=2)
+            n_if = nb // 2 // int(p.rf_decim)
+            warm = 2 if 6 * n_if < 7_500_000 else 1
+            ms = event_ms(torch, fn, max(2, min(8, 7_500_000 // n_if - warm)), warm=warm)
         else:
             ms = event_ms(torch, fn, k, warm=5)
         nm, d = leg(name, what, nb // 2, ms, bytes_per_sample)
@@ -320,8 +323,10 @@ def side_legs(torch, fmrx, synth, args, pl, step, d_iq, n_bytes, stream) -> dict
     mode_leg("mode1_mono", 1, 1, 64, "mode 1 mono (1.44 MS/s, decim 5 x 6), fused kernel, 64 blocks of 614,400 samples", 2.0 + 2.0 / 30.0, 1228800)
     mode_leg("mode2_mono", 2, 1, 63, "mode 2 mono (U/D = 147/800 resampler), 63 blocks of 1,008,000 samples", 2.0 + 2.0 * 147 / 8000.0, 2016000)
     mode_leg("mode3_mono", 3, 1, 63, "mode 3 mono (960 kS/s, U/D = 441/3200), 63 blocks of 1,008,000 samples", 2.0 + 2.0 * 441 / 9600.0, 2016000)
-    mode_leg("mode0_stereo", 0, 2, 12, "mode 0 stereo (pilot PLL + 38 kHz mixer + L/R), s16 L,R out, 12 x 1,024,000-sample blocks per step, stream continued",
+    mode_leg("mode0_stereo", 0, 2, 12, "mode 0 stereo (pilot PLL + 38 kHz mixer + L/R), s16 L,R out, 12 x 1,024,000-sample blocks per step, stream continued (its first 31 s)",
              2.0 + 4.0 / 50.0, 2048000, base_blocks=3)
+    mode_leg("mode0_stereo_24_blocks", 0, 2, 24, "mode 0 stereo, 24 x 1,024,000-sample blocks per step (the PLL's 128-step lanes are a fixed cost per "
+             "call up to ~40 blocks), stream continued", 2.0 + 4.0 / 50.0, 2048000, base_blocks=3)
     # (5) a live channel's regime: reference-size blocks (51,200 samples), one call per block, device-resident
     q = fmrx.Pipeline(0, 1, device=torch.cuda.current_device())
     d_pcm = torch.empty(1024, dtype=torch.int16, device="cuda")

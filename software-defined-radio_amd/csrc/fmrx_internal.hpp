@@ -245,7 +245,8 @@ constexpr int kPllHead = 1024;   // samples of a stream's first call walked seri
 constexpr float kPllTolPhase = 1e-2f, kPllTolInteg = 1e-4f;
 size_t pll_parallel_scratch_floats(size_t n);
 int k_fm_pll_parallel(const float *d_in, size_t n, float *d_out, float *d_state, float freq, float Fs, float ncoScale,
-                      float phaseAdjust, float normBandwidth, float *d_scratch, const Options &o, hipStream_t s);
+                      float phaseAdjust, float normBandwidth, float *d_scratch, const Options &o, hipStream_t s,
+                      double off_hint = -1.0);   // off_hint: IF samples of the stream in front of this call (the state's trigOffset), < 0 = unknown
 int k_mix(const float *d_bpf, const float *d_pll, size_t n, float *d_mix, hipStream_t s);
 int k_combine(const float *d_st, const float *d_mono, size_t n, float *d_l, float *d_r, hipStream_t s);
 int k_upsample(const float *d_x, size_t n, float *d_xu, int up, hipStream_t s);

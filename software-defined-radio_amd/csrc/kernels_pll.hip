@@ -654,12 +654,18 @@ size_t pll_parallel_scratch_floats(size_t n)
 }
 
 int k_fm_pll_parallel(const float *d_in, size_t n, float *d_out, float *d_state, float freq, float Fs, float ncoScale,
-                      float phaseAdjust, float normBandwidth, float *d_scratch, const Options &o, hipStream_t s)
+                      float phaseAdjust, float normBandwidth, float *d_scratch, const Options &o, hipStream_t s, double off_hint)
 {
     int L = kPllSegment, W = kPllWarmup;
     if (o.pll_warmup >= 0 && o.pll_warmup <= 65536) W = o.pll_warmup / 4 * 4;                    // tuning: warm-up samples per lane
     if (o.pll_segment >= kPllSegmentMin && o.pll_segment <= 65536) L = o.pll_segment / 4 * 4;   // tuning: samples per lane
-    if (o.pll_start == 1) {
+    // The linear-system start holds while the float32 grid of trigArg is a perturbation of the loop (ulp <= 0.25 rad: the
+    // first 2^22 rad = 8.4 M IF samples = 35 s of a stream, measured to 27.7 s); beyond that the grid IS the loop's
+    // dynamics and only true steps reproduce it: the lanes then start the first way.  off_hint = the caller's count of the
+    // stream's IF samples in front of this call (< 0: unknown).
+    const double w = 2 * 3.14159265358979323846 * static_cast<double>(freq / Fs);
+    const bool lti = o.pll_start == 1 && off_hint >= 0.0 && w * (off_hint + static_cast<double>(n)) < 4194304.0;
+    if (lti) {
         // lanes start from the linear system's state (see pll_lti_chunks_kernel): W, L in whole 64-sample chunks
         if (o.pll_warmup < 0) W = kPllWarmupLti;
         W = (W + kLtiChunk - 1) / kLtiChunk * kLtiChunk;
@@ -672,7 +678,7 @@ int k_fm_pll_parallel(const float *d_in, size_t n, float *d_out, float *d_state,
     PllCoef c = make_coef(freq, Fs, ncoScale, phaseAdjust, normBandwidth);
     // the loop's state repeats every P samples on an on-frequency pilot: Fs / gcd(Fs, freq), when both are whole Hz
     int P = 0;
-    if (o.pll_align != 0 && o.pll_start != 1 && Fs == static_cast<float>(static_cast<long>(Fs)) && freq == static_cast<float>(static_cast<long>(freq)) && freq > 0) {
+    if (o.pll_align != 0 && !lti && Fs == static_cast<float>(static_cast<long>(Fs)) && freq == static_cast<float>(static_cast<long>(freq)) && freq > 0) {
         long x = static_cast<long>(Fs), y = static_cast<long>(freq);
         while (y) { const long t = x % y; x = y; y = t; }
         const long p = static_cast<long>(Fs) / x;
@@ -686,7 +692,7 @@ int k_fm_pll_parallel(const float *d_in, size_t n, float *d_out, float *d_state,
     unsigned long long *badmask = reinterpret_cast<unsigned long long *>(seg + (nseg + 1) * 16);
     const unsigned grid = static_cast<unsigned>((nseg + 63) / 64);
     const double *lti_rec = nullptr, *lti_wgtot = nullptr;
-    if (o.pll_start == 1) {
+    if (lti) {
         c.integ_tol_ulps = kPllIntegTolUlpsLti;
         const long nchunk = static_cast<long>(n / kLtiChunk) + 1;
         const size_t mask_floats = 2 * (static_cast<size_t>(nseg) / 64 + 2);

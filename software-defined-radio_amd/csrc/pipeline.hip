@@ -44,6 +44,7 @@ struct fmrx_pipeline {
     bool demod_valid = true;     // the demod buffer holds the whole last block (not just its tail: fused mono kernel)
     bool mixer_valid = false;    // the mixer output of the last block was stored (the fused stereo kernel keeps it on chip)
     bool pll_warm = false;       // the PLL has seen a block since reset / set_state (its state is a locked one)
+    double pll_off = 0.0;        // host copy of the PLL's trigOffset (IF samples since the stream began, as the reference counts them)
     Options opt;                 // copied from the process defaults at creation; fmrx_pipeline_set_option
 
     hipStream_t stream = nullptr;  // used by the host-buffer entry point
@@ -139,6 +140,7 @@ int reset_state(fmrx_pipeline *pl)
     pl->prev_override = false;
     pl->if_valid = false;
     pl->pll_warm = false;
+    pl->pll_off = 0.0;
     return FMRX_OK;
 }
 
@@ -492,9 +494,11 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
             }
             if (n_if > head)
                 FMRX_TRY(k_fm_pll_parallel(pl->carrier.p + head, n_if - head, pl->pll.p + head, pl->pll_state.p, 19e3f,
-                                           static_cast<float>(p.if_Fs), 2.0f, 0.0f, 0.01f, pl->pll_scratch.p, pl->opt, s));
+                                           static_cast<float>(p.if_Fs), 2.0f, 0.0f, 0.01f, pl->pll_scratch.p, pl->opt, s,
+                                           pl->pll_off + static_cast<double>(head)));
             pl->pll_warm = true;
         }
+        pl->pll_off += static_cast<double>(n_if);
         const float *tail_in = pl->mix_tail[pl->mix_cur].p;
         float *tail_out = pl->mix_tail[pl->mix_cur ^ 1].p;
         if (fused_out) {
@@ -690,6 +694,7 @@ int fmrx_pipeline_set_state(fmrx_pipeline *pl, const float *state, size_t n)
         FMRX_HIP(hipMemset(pl->mix_tail[pl->mix_cur].p, 0, pl->Hm * sizeof(float)));
         FMRX_HIP(hipMemcpy(pl->mix_tail[pl->mix_cur].p + (pl->Hm - pl->Ha), s_sf, pl->Ha * sizeof(float), hipMemcpyHostToDevice));
         FMRX_HIP(hipMemcpy(pl->pll_state.p, o, 6 * sizeof(float), hipMemcpyHostToDevice));
+        pl->pll_off = static_cast<double>(o[5]);                   // trigOffset (src/filter.cpp:37)
         o += 6;
     } else {
         std::memcpy(dend - pl->Ha, s_mono, pl->Ha * sizeof(float));
