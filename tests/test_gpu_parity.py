@@ -752,6 +752,28 @@ def test_stereo_parallel_pll_matches_serial(fmrx, oracle, pll_start):
     assert rep == 0 and dp <= 5e-3          # a clean locked signal: every segment merged
 
 
+def test_stereo_parallel_pll_late_in_a_stream(fmrx, oracle):
+    """35 s into a stream the float32 trigArg resolves 0.5 rad: the linear-system start of the PLL's lanes (which treats
+    that grid as a perturbation) hands over to long warm-ups of true steps (kernels_pll.hip: k_fm_pll_parallel).  Nine
+    12,288,000-sample calls cross that point (1.23 M IF samples each, 8.39 M at the hand-over): every call agrees with the
+    same recurrence walked serially (pll_mode 1) to within the envelope, before, across and after it, without repairs."""
+    n = 1024000
+    base = oracle.synth_fm_u8(3 * n, seed=0x3D74)          # 1280 periods of the multiplex: tiles seamlessly
+    iq = np.tile(base, 4)
+    par = fmrx.Pipeline(0, 2, max_block_bytes=iq.size)
+    ser = fmrx.Pipeline(0, 2, max_block_bytes=iq.size)
+    ser.set_option("pll_mode", 1)
+    for step in range(9):
+        a, b = par.process(iq), ser.process(iq)
+        t_end = (step + 1) * 12 * n / 2.4e6
+        u = float(trig_arg_ulp(t_end))
+        d = max(rms(a[k].astype(np.float64) - b[k]) for k in ("audio_l", "audio_r"))
+        print(f"step {step}: t = {t_end:.1f} s, ulp(trigArg) {u:.3g}, parallel vs serial rms {d:.2e} = {d / u:.3f} ulp, "
+              f"repaired so far {par.pll_diagnostics()[0]}")
+        assert d <= ENVELOPE_FACTOR * u, (step, d, u)
+    assert par.pll_diagnostics()[0] <= 4
+
+
 @pytest.mark.parametrize("pll_start", PLL_STARTS)
 def test_stereo_parallel_pll_survives_phase_jumps(fmrx, oracle, pll_start):
     """A pilot phase jump in the middle of a block (two unrelated streams spliced) un-locks the loop.
