@@ -212,7 +212,7 @@ __global__ void nco_out_kernel(float *__restrict__ out, size_t n, PllCoef c)
 // What this ignores is the float32 grid of trigArg (the true loop sees theta rounded to ulp(trigArg)): the lanes
 // therefore still run W true steps from there before their own segment.  A sign pattern that is not a locked
 // pilot's (a glitch: two sign changes within a sample or two) breaks the staircase rule; the lanes' ends then do not
-// meet their successors' starts and pll_check_nco / pll_repair walk those stretches serially, as before.
+// meet their successors' starts and pll_repair_kernel walks those stretches serially, as before.
 constexpr int kLtiTerms = 20;          // (A^64)^20 ~ 5e-8: what is dropped of the state 1280 samples back
 struct LtiMat {
     double a00, a01, a10, a11, b0, b1;   // s' = A s + B x, s = (phi, iota)
@@ -335,6 +335,32 @@ __device__ __forceinline__ void lti_start_state(const LtiStart &L, const double 
     phase = static_cast<float>((L.phi0 + p) * 6.28318530717958647692);
 }
 
+// The loop cannot tell phases apart that round to the same float32 trigArg, so the merge
+// tolerance follows that grid: base + 2 ulp(trigArg) at the end of the block (ulp grows from 1e-3
+// at 1e4 rad to 0.25 at 3e6 rad -- the reference's own resolution loss, SURVEY Q9).
+__device__ __forceinline__ float pll_trig_ulp(const float *state, long n, const PllCoef &c)
+{
+    const float top = static_cast<float>(c.w * (static_cast<double>(state[5]) + static_cast<double>(n)));
+    return __uint_as_float((__float_as_uint(top) & 0x7f800000u)) * 1.1920929e-7f;   // 2^(e-23)
+}
+// Two phase estimates that differ by whole turns stand for the same loop state (trigArg only enters through sin / cos and the
+// NCO's cos): a lane that counted one pilot cycle more or less than its neighbour is not wrong.  |a - b| modulo 2 pi.
+__device__ __forceinline__ float pll_phase_dist(float a, float b)
+{
+    const float d = a - b;
+    return fabsf(d - 6.28318530717958647692f * rintf(d * 0.15915494309189533577f));
+}
+__device__ __forceinline__ float pll_phase_tol(float base, const float *state, long n, const PllCoef &c)
+{
+    return base + 2.0f * pll_trig_ulp(state, n, c);
+}
+// the integrator moves by Ki * (phase error) per sample, and the phase error is only known to that
+// grid: two trajectories cannot agree better than a couple of such steps
+__device__ __forceinline__ float pll_integ_tol(float base, const float *state, long n, const PllCoef &c)
+{
+    return base + c.integ_tol_ulps * c.Ki * pll_trig_ulp(state, n, c);
+}
+
 // ---- parallel in time -------------------------------------------------------------------------
 // seg[s*16 + 0..5]  state at the END of segment s      (after sample a_s + L - 1; fbI/fbQ/last finished)
 // seg[s*16 + 8..9]  (integ, phase) this lane had at the START of segment s (after its warm-up)
@@ -350,7 +376,8 @@ __device__ __forceinline__ void lti_start_state(const LtiStart &L, const double 
 __global__ void pll_segments_kernel(const float *__restrict__ in, long n, float *__restrict__ out,
                                     const float *__restrict__ state, PllCoef c, int L, int W, int P, long nseg,
                                     float *__restrict__ seg, float *hdr, const double *__restrict__ lti_rec,
-                                    const double *__restrict__ lti_wgtot)
+                                    const double *__restrict__ lti_wgtot, unsigned long long *__restrict__ badmask,
+                                    float tol_phase_base, float tol_integ_base)
 {
     const long sg = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
     // linear-system start: the climb of the chunk workgroups in front of the one this wave's first lane starts in, summed by
@@ -423,10 +450,8 @@ __global__ void pll_segments_kernel(const float *__restrict__ in, long n, float 
     }
     seg[sg * 16 + 8] = s.integ;
     seg[sg * 16 + 9] = s.phase;
-    if (sg == 0) {
-        out[0] = s0.last;
-        hdr[1] = 0.0f;                                     // "some segment needs repair": set by pll_check_nco_kernel
-    }
+    const float start_integ = s.integ, start_phase = s.phase;
+    if (sg == 0) out[0] = s0.last;
     for (; k + 4 <= b; k += 4) {
         const f4 cur = q0;
         q0 = q1;
@@ -456,65 +481,36 @@ __global__ void pll_segments_kernel(const float *__restrict__ in, long n, float 
     }
     finish_state<kFast>(s, c);
     store_state(seg + sg * 16, s);
-}
-
-// The loop cannot tell phases apart that round to the same float32 trigArg, so the merge
-// tolerance follows that grid: base + 2 ulp(trigArg) at the end of the block (ulp grows from 1e-3
-// at 1e4 rad to 0.25 at 3e6 rad -- the reference's own resolution loss, SURVEY Q9).
-__device__ __forceinline__ float pll_trig_ulp(const float *state, long n, const PllCoef &c)
-{
-    const float top = static_cast<float>(c.w * (static_cast<double>(state[5]) + static_cast<double>(n)));
-    return __uint_as_float((__float_as_uint(top) & 0x7f800000u)) * 1.1920929e-7f;   // 2^(e-23)
-}
-// Two phase estimates that differ by whole turns stand for the same loop state (trigArg only enters through sin / cos and the
-// NCO's cos): a lane that counted one pilot cycle more or less than its neighbour is not wrong.  |a - b| modulo 2 pi.
-__device__ __forceinline__ float pll_phase_dist(float a, float b)
-{
-    const float d = a - b;
-    return fabsf(d - 6.28318530717958647692f * rintf(d * 0.15915494309189533577f));
-}
-__device__ __forceinline__ float pll_phase_tol(float base, const float *state, long n, const PllCoef &c)
-{
-    return base + 2.0f * pll_trig_ulp(state, n, c);
-}
-// the integrator moves by Ki * (phase error) per sample, and the phase error is only known to that
-// grid: two trajectories cannot agree better than a couple of such steps
-__device__ __forceinline__ float pll_integ_tol(float base, const float *state, long n, const PllCoef &c)
-{
-    return base + c.integ_tol_ulps * c.Ki * pll_trig_ulp(state, n, c);
-}
-
-// Judge.  Every thread judges one segment: its lane's start state against its predecessor's end state, to the merge
-// tolerance (the mask words are written whole: no memset); the largest accepted differences are kept for diagnostics.
-// (Judge and finish in ONE launch -- the last workgroup to take a ticket doing the rest -- was measured: the device-scope
-// fences it needs cost more than the second launch, 10.2 vs 7 us.)
-constexpr int kCheckThreads = 256;
-__global__ __launch_bounds__(kCheckThreads) void pll_check_kernel(
-    const float *__restrict__ seg, long nseg, unsigned long long *__restrict__ badmask, float tol_phase_base, float tol_integ_base,
-    unsigned *__restrict__ diag, const float *__restrict__ state, long n, PllCoef c)
-{
-    const float tol_phase = pll_phase_tol(tol_phase_base, state, n, c);
-    const float tol_integ = pll_integ_tol(tol_integ_base, state, n, c);
-    const long sg = static_cast<long>(blockIdx.x) * kCheckThreads + threadIdx.x;
-    bool bad = false;
-    float dp = 0.0f, di = 0.0f;
-    if (sg >= 1 && sg < nseg) {
-        di = fabsf(seg[sg * 16 + 8] - seg[(sg - 1) * 16 + 0]);
-        dp = pll_phase_dist(seg[sg * 16 + 9], seg[(sg - 1) * 16 + 1]);
-        bad = !(dp <= tol_phase && di <= tol_integ);
-        if (bad) dp = di = 0.0f;
-    }
-    const unsigned long long m = __ballot(bad);
-    for (int o = 32; o; o >>= 1) {
-        dp = fmaxf(dp, __shfl_xor(dp, o, 64));
-        di = fmaxf(di, __shfl_xor(di, o, 64));
-    }
-    if ((threadIdx.x & 63) == 0 && sg / 64 <= (nseg - 1) / 64) {
-        badmask[sg / 64] = m;
-        if (m) reinterpret_cast<float *>(diag)[1] = 1.0f;          // every writer writes the same value
-        // read before the atomic: hundreds of waves hammering two addresses cost more than the rest of the kernel
-        if (__float_as_uint(dp) > diag[3]) atomicMax(diag + 3, __float_as_uint(dp));   // non-negative floats order like their bit patterns
-        if (__float_as_uint(di) > diag[4]) atomicMax(diag + 4, __float_as_uint(di));
+    // Judge: this lane's start state against its predecessor's end state, to the merge tolerance.  The predecessor is the
+    // lane next door (the wave's lanes are 64 consecutive segments and have all arrived here); the wave's first lane has
+    // its predecessor in another workgroup: pll_repair_kernel judges those (bit 0 of every mask word is left clear).
+    // The mask words are written whole: no memset.
+    {
+        const float tol_phase = pll_phase_tol(tol_phase_base, state, n, c);
+        const float tol_integ = pll_integ_tol(tol_integ_base, state, n, c);
+        const float pe_integ = __shfl_up(s.integ, 1, 64), pe_phase = __shfl_up(s.phase, 1, 64);
+        bool bad = false;
+        float dp = 0.0f, di = 0.0f;
+        if (threadIdx.x > 0) {
+            di = fabsf(start_integ - pe_integ);
+            dp = pll_phase_dist(start_phase, pe_phase);
+            bad = !(dp <= tol_phase && di <= tol_integ);
+            if (bad) dp = di = 0.0f;
+        }
+        const unsigned long long m = __ballot(bad);
+        for (int o = 32; o; o >>= 1) {
+            dp = fmaxf(dp, __shfl_xor(dp, o, 64));
+            di = fmaxf(di, __shfl_xor(di, o, 64));
+        }
+        if (threadIdx.x == 0) {
+            unsigned *diag = reinterpret_cast<unsigned *>(hdr);
+            badmask[sg / 64] = m;
+            if (m) hdr[1] = 1.0f;                              // "some segment needs repair"; cleared by pll_repair_kernel
+            // the largest accepted differences (diagnostics).  Read before the atomic: hundreds of waves hammering two
+            // addresses cost more than the rest
+            if (__float_as_uint(dp) > diag[3]) atomicMax(diag + 3, __float_as_uint(dp));   // non-negative floats order like their bit patterns
+            if (__float_as_uint(di) > diag[4]) atomicMax(diag + 4, __float_as_uint(di));
+        }
     }
 }
 
@@ -530,9 +526,29 @@ __global__ __launch_bounds__(kRepairThreads) void pll_repair_kernel(
     __shared__ int any_todo;
     const float tol_phase = pll_phase_tol(tol_phase_base, state, n, c);
     const float tol_integ = pll_integ_tol(tol_integ_base, state, n, c);
-    auto is_bad = [&](long sg) { return (badmask[sg / 64] >> (sg % 64)) & 1ull; };
+    // the segments whose predecessor ran in another workgroup (every 64th): judged here
+    __shared__ int flagged;
+    if (threadIdx.x == 0) flagged = hdr[1] != 0.0f;
+    __syncthreads();
+    {
+        unsigned *diag = reinterpret_cast<unsigned *>(hdr);
+        for (long sg = 64 * (1 + static_cast<long>(threadIdx.x)); sg < nseg; sg += 64 * kRepairThreads) {
+            const float di = fabsf(seg[sg * 16 + 8] - seg[(sg - 1) * 16 + 0]);
+            const float dp = pll_phase_dist(seg[sg * 16 + 9], seg[(sg - 1) * 16 + 1]);
+            if (!(dp <= tol_phase && di <= tol_integ)) {
+                atomicOr(badmask + sg / 64, 1ull);
+                flagged = 1;
+            } else {
+                if (__float_as_uint(dp) > diag[3]) atomicMax(diag + 3, __float_as_uint(dp));
+                if (__float_as_uint(di) > diag[4]) atomicMax(diag + 4, __float_as_uint(di));
+            }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    auto is_bad = [&](long sg) { return (__atomic_load_n(badmask + sg / 64, __ATOMIC_RELAXED) >> (sg % 64)) & 1ull; };
     unsigned repaired = 0;
-    const bool nothing_to_do = hdr[1] == 0.0f;             // the common case: every segment merged
+    const bool nothing_to_do = !flagged;                   // the common case: every segment merged
     for (; !nothing_to_do;) {
         if (threadIdx.x == 0) any_todo = 0;
         __syncthreads();
@@ -575,6 +591,7 @@ __global__ __launch_bounds__(kRepairThreads) void pll_repair_kernel(
     if (n_repaired && repaired) atomicAdd(n_repaired, repaired);
     if (threadIdx.x == 0) {
         // remember where this call's phase started, for the next call's extrapolation (pll_start = 0)
+        hdr[1] = 0.0f;                                         // for the next call's lanes to raise again
         hdr[5] = state[1];
         hdr[6] = static_cast<float>(n);
         hdr[7] = 1.0f;
@@ -707,11 +724,8 @@ int k_fm_pll_parallel(const float *d_in, size_t n, float *d_out, float *d_state,
         lti_wgtot = wgtot;
     }
     hipLaunchKernelGGL(pll_segments_kernel, dim3(grid), dim3(64), 0, s, d_in, static_cast<long>(n), d_out, d_state, c, L, W, P,
-                       nseg, seg, d_scratch, lti_rec, lti_wgtot);
+                       nseg, seg, d_scratch, lti_rec, lti_wgtot, badmask, kPllTolPhase, kPllTolInteg);
     FMRX_LAUNCH_CHECK("pll_segments");
-    hipLaunchKernelGGL(pll_check_kernel, dim3(static_cast<unsigned>((nseg + kCheckThreads - 1) / kCheckThreads)), dim3(kCheckThreads), 0, s,
-                       seg, nseg, badmask, kPllTolPhase, kPllTolInteg, reinterpret_cast<unsigned *>(d_scratch), d_state, static_cast<long>(n), c);
-    FMRX_LAUNCH_CHECK("pll_check");
     hipLaunchKernelGGL(pll_repair_kernel, dim3(1), dim3(kRepairThreads), 0, s, d_in, static_cast<long>(n), d_out, d_state, c, L, nseg, seg,
                        badmask, kPllTolPhase, kPllTolInteg, n_repaired, d_scratch);
     FMRX_LAUNCH_CHECK("pll_repair");
