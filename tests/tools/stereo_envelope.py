@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Stereo error vs stream time, cause by cause: the same 2.13 s mode-0 stereo stream
 through the GPU pipeline in four configurations, each against the oracle (= the compiled reference, bit for
-bit) for the whole stream, RMS error of the left channel per {win / 48000.0:.1f} s window, in absolute terms and in units of
+bit) for the whole stream, RMS error of the left channel per {win / au_Fs:.1f} s window, in absolute terms and in units of
 ulp(trigArg(t)):
    fast / parallel   default: specialised kernels, parallel-in-time PLL, fast math (closed-form phase detector)
    fast / serial     pll_mode 1: same math, serial recurrence               -> isolates the segment merge
@@ -28,15 +28,21 @@ def ulp(t):
 
 
 def main():
-    bb = int(sys.argv[1]) if len(sys.argv) > 1 else 2 * 1024000
+    bb_arg = sys.argv[1] if len(sys.argv) > 1 else str(2 * 1024000)      # bytes per call, or xN = N reference blocks
     nblk = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     o = Oracle()
-    p = o.mode_params(0, 101, 101, 101)
+    p = o.mode_params(mode, 101, 101, 101)
+    bb = p.block_bytes * int(bb_arg[1:]) if bb_arg.startswith('x') else int(bb_arg)
     iq = o.synth_fm_u8(p.block_bytes // 2 * nblk, rf_Fs=p.rf_Fs, seed=0x3D74)
-    po = o.pipeline(0, 2)
+    po = o.pipeline(mode, 2)
     Lo = np.concatenate([po.process(iq[k:k + p.block_bytes])["audio_l"] for k in range(0, len(iq), p.block_bytes)])
-    win = 4800 if nblk <= 200 else 48000          # 0.1 s windows (1 s for long streams)
-    t_end = (np.arange(len(Lo) // win) + 1) * (win / 48000.0)
+    if_Fs = p.rf_Fs / p.rf_decim
+    au_Fs = len(Lo) / (len(iq) / 2 / p.rf_Fs)                     # audio samples per second
+    win = int(round(au_Fs * (0.1 if nblk <= 200 else 1.0)))       # 0.1 s windows (1 s for long streams)
+    t_end = (np.arange(len(Lo) // win) + 1) * (win / au_Fs)
+    global ulp
+    ulp = lambda t: 2.0 ** (np.floor(np.log2(2 * np.pi * 19e3 / if_Fs * np.maximum(if_Fs * np.asarray(t, np.float64), 1.0))) - 23)
     rows = {}
     diag = {}
     sets = {"default": (("fast/parallel", {}), ("fast/serial", {"pll_mode": 1}), ("fast/glibc", {"pll_mode": 2}),
@@ -47,7 +53,7 @@ def main():
                     ("lti W128", {"pll_start": 1, "pll_warmup": 128}), ("lti W256", {"pll_start": 1, "pll_warmup": 256}),
                     ("fast/serial", {"pll_mode": 1}))}
     for name, cfg in sets[sys.argv[3] if len(sys.argv) > 3 else "default"]:
-        pl = fmrx.Pipeline(0, 2, max_block_bytes=bb)
+        pl = fmrx.Pipeline(mode, 2, max_block_bytes=bb)
         for k, v in cfg.items():
             if k == "generic":
                 pl.set_force_generic(True)
@@ -61,8 +67,8 @@ def main():
         d = (L[:n].astype(np.float64) - Lo[:n]).reshape(-1, win)
         rows[name] = (np.sqrt(np.mean(d * d, axis=1)), dt)
     names = list(rows)
-    print(f"# mode 0 stereo, {nblk} reference blocks = {nblk * 51200 / 2.4e6:.2f} s, fed as {bb}-byte blocks; "
-          f"left-channel RMS error vs the oracle per {win / 48000.0:.1f} s window: absolute (in ulp(trigArg))")
+    print(f"# mode {mode} stereo, {nblk} reference blocks = {len(iq) / 2 / p.rf_Fs:.2f} s, fed as {bb}-byte blocks; "
+          f"left-channel RMS error vs the oracle per {win / au_Fs:.1f} s window: absolute (in ulp(trigArg))")
     print("t_end[s]  ulp(trigArg)  " + "  ".join(f"{n:>22s}" for n in names))
     for i, t in enumerate(t_end[: len(rows[names[0]][0])]):
         print(f"{t:7.1f}  {ulp(t):11.2e}  " + "  ".join(f"{rows[n][0][i]:12.2e} ({rows[n][0][i] / ulp(t):5.3f})" for n in names))
