@@ -575,6 +575,22 @@ def test_real_signal_block(fmrx, oracle):
         bits_equal(out["audio"], g[f"{tag}_audio"]); bits_equal(out["pcm16"], g[f"{tag}_s16"])  # incl. wrapped samples
 
 
+def test_real_signal_block_stereo(fmrx, oracle):
+    """The reference's one real capture through the STEREO pipeline: a noisy signal on which the pilot loop does not hold lock
+    (discriminator spikes), i.e. the case the parallel PLL's lanes are not made for.  The default path must still agree with the
+    oracle as well as the serial fast recurrence does (its lanes do not meet, so the repair kernel walks them: tools:
+    tests/tools/real_capture_stereo.py), relative to the (large) signal RMS."""
+    iq = np.fromfile(os.path.join(G, "pipe_iq_102400.u8"), np.uint8)
+    ref = oracle.pipeline(0, 2).process(iq)
+    par, ser = fmrx.Pipeline(0, 2), fmrx.Pipeline(0, 2)
+    ser.set_option("pll_mode", 1)
+    a, b = par.process(iq), ser.process(iq)
+    for k in ("audio_l", "audio_r"):
+        ea, eb = rel_rms(a[k], ref[k]), rel_rms(b[k], ref[k])
+        print(k, "parallel", ea, "serial", eb, "repaired", par.pll_diagnostics()[0])
+        assert eb <= 1e-4 and ea <= max(1e-4, 2 * eb), (k, ea, eb)
+
+
 @pytest.mark.parametrize("fe", FE_VARIANTS)
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_stereo_pipeline(fmrx, oracle, mode, fe):
