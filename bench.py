@@ -320,7 +320,7 @@ def side_legs(torch, fmrx, synth, args, pl, step, d_iq, n_bytes, stream) -> dict
         legs[nm] = d
         q.close()
 
-    mode_leg("mode1_mono", 1, 1, 64, "mode 1 mono (1.44 MS/s, decim 5 x 6), fused kernel, 64 blocks of 614,400 samples", 2.0 + 2.0 / 30.0, 1228800)
+    mode_leg("mode1_mono", 1, 1, 256, "mode 1 mono (1.44 MS/s, decim 5 x 6), fused kernel, 256 blocks of 614,400 samples", 2.0 + 2.0 / 30.0, 1228800)
     mode_leg("mode2_mono", 2, 1, 63, "mode 2 mono (U/D = 147/800 resampler), 63 blocks of 1,008,000 samples", 2.0 + 2.0 * 147 / 8000.0, 2016000)
     mode_leg("mode3_mono", 3, 1, 63, "mode 3 mono (960 kS/s, U/D = 441/3200), 63 blocks of 1,008,000 samples", 2.0 + 2.0 * 441 / 9600.0, 2016000)
     mode_leg("mode0_stereo", 0, 2, 12, "mode 0 stereo (pilot PLL + 38 kHz mixer + L/R), s16 L,R out, 12 x 1,024,000-sample blocks per step, stream continued (its first 31 s)",
