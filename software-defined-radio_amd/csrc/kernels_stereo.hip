@@ -153,17 +153,41 @@ __global__ __launch_bounds__(NT) void stereo_out_kernel(const float *__restrict_
     const long g0 = D * a0 - (T - 1);                      // IF index of window sample 0
     // D-1 samples past the window are visited too: when the block ends exactly on a tile boundary nobody's window
     // reaches the block's last D-1 samples, and they belong to the tail this call leaves behind
-    for (int j = t; j < WL + D - 1; j += NT) {
+    // every load of the staging in flight before the first LDS write (a loop of load -> branch -> store pays one HBM / L2 round
+    // trip per iteration: 11 of them were most of this kernel's time)
+    constexpr int NJ = (WL + D - 1 + NT - 1) / NT;
+    float vm[NJ], va[NJ], vb[NJ];
+#pragma unroll
+    for (int q = 0; q < NJ; q++) {
+        const int j = t + q * NT;
         const long g = g0 + j;
+        const bool valid = j < WL + D - 1 && g < n_if;
+        vm[q] = 0.0f;
+        va[q] = 0.0f;
+        vb[q] = 0.0f;
+        if (valid) {
+            vm[q] = demod[g - delay];                          // history in front of the buffer: negative indices are valid
+            const float *pa = g >= 0 ? bpf + g : mix_tail_in + (hm + g);
+            va[q] = *pa;
+            if (g >= 0) vb[q] = nco[g];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NJ; q++) asm volatile("" : "+v"(vm[q]), "+v"(va[q]), "+v"(vb[q]));
+#pragma unroll
+    for (int q = 0; q < NJ; q++) {
+        const int j = t + q * NT;
+        const long g = g0 + j;
+        if (j >= WL + D - 1) continue;
         float m = 0.0f, x = 0.0f;
         if (g < n_if) {
-            m = demod[g - delay];                          // history in front of the buffer: negative indices are valid
+            m = vm[q];
             if (g >= 0) {
-                x = (bpf[g] * nco[g]) * 2.0f;              // the reference's order: (stereo_filt * PLL) * 2
+                x = (va[q] * vb[q]) * 2.0f;                    // the reference's order: (stereo_filt * PLL) * 2
                 if (mixer_out) mixer_out[g] = x;
                 if (g >= n_if - hm) mix_tail_out[g - (n_if - hm)] = x;
             } else {
-                x = mix_tail_in[hm + g];
+                x = va[q];
                 if (n_if < hm && hm + g >= n_if) mix_tail_out[hm + g - n_if] = x;   // a block shorter than the history keeps what it must
             }
         }
