@@ -50,9 +50,23 @@ __global__ void channels_finish_kernel(uint8_t *__restrict__ slots, long slot_by
     const long c = blockIdx.y;
     uint8_t *slot = slots + c * slot_bytes;
     const long t = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x, nt = static_cast<long>(gridDim.x) * blockDim.x;
-    for (long k = t; k < n_audio; k += nt) {
-        if (audio_out) audio_out[c * n_audio + k] = audio_all[c * slot_audio + junk_audio + k];
-        if (pcm_out) pcm_out[c * n_audio + k] = pcm_all[c * slot_audio + junk_audio + k];
+    const long so = c * slot_audio + junk_audio, dof = c * n_audio;   // first element of this channel: source, destination
+    // four outputs per access where source and destination allow it (8-byte s16 / 16-byte f32 pieces): true for every reference
+    // shape (52 600 / 1 024 elements per slot / channel, 28 in front)
+    if (n_audio % 4 == 0 && so % 4 == 0 && dof % 4 == 0 && (!pcm_out || (reinterpret_cast<uintptr_t>(pcm_out) % 8 == 0 &&
+        reinterpret_cast<uintptr_t>(pcm_all) % 8 == 0)) && (!audio_out || (reinterpret_cast<uintptr_t>(audio_out) % 16 == 0 &&
+        reinterpret_cast<uintptr_t>(audio_all) % 16 == 0))) {
+        typedef short s4v __attribute__((ext_vector_type(4)));
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        for (long k = t; k < n_audio / 4; k += nt) {
+            if (audio_out) reinterpret_cast<f4v *>(audio_out + dof)[k] = reinterpret_cast<const f4v *>(audio_all + so)[k];
+            if (pcm_out) reinterpret_cast<s4v *>(pcm_out + dof)[k] = reinterpret_cast<const s4v *>(pcm_all + so)[k];
+        }
+    } else {
+        for (long k = t; k < n_audio; k += nt) {
+            if (audio_out) audio_out[dof + k] = audio_all[so + k];
+            if (pcm_out) pcm_out[dof + k] = pcm_all[so + k];
+        }
     }
     // history: 16-byte pieces; source and destination overlap only if the block is shorter than the history, which
     // create() rejects, so a plain copy is safe whatever the order
@@ -168,7 +182,8 @@ int fmrx_channels_process_dev(fmrx_channels *c, float *d_audio_f32, int16_t *d_p
     const float *zend = c->zeros.p + c->p.audio_taps + 32;     // "one past the previous block's last discriminator sample": zeros
     FMRX_TRY(mono_fused_launch(c->fe, c->audio, c->slots.p, total / 2, c->fe.silence.p, c->zeros.p, zend, nullptr, 0, nullptr,
                                d_audio_f32 ? c->audio_all.p : nullptr, c->pcm_all.p, pcm_policy, nullptr, c->opt, s));
-    const unsigned gx = static_cast<unsigned>((c->n_audio + 255) / 256 < 8 ? (c->n_audio + 255) / 256 : 8);
+    const size_t per4 = (c->n_audio + 3) / 4;                  // four outputs per thread where the shapes allow it (see the kernel)
+    const unsigned gx = static_cast<unsigned>((per4 + 255) / 256 < 8 ? (per4 + 255) / 256 : 8);
     hipLaunchKernelGGL(channels_finish_kernel, dim3(gx ? gx : 1, c->n_channels), dim3(256), 0, s, c->slots.p,
                        static_cast<long>(c->slot_bytes), static_cast<long>(c->hist_bytes), c->audio_all.p, c->pcm_all.p,
                        static_cast<long>(c->junk_audio + c->n_audio), static_cast<long>(c->junk_audio), static_cast<long>(c->n_audio),
