@@ -768,6 +768,30 @@ def test_stereo_parallel_pll_matches_serial(fmrx, oracle, pll_start):
     assert rep == 0 and dp <= 5e-3          # a clean locked signal: every segment merged
 
 
+@pytest.mark.parametrize("mode,seconds", [(0, 12.0), (1, 6.0), (2, 6.0), (3, 9.0)])
+def test_stereo_error_envelope_seconds_into_a_stream(fmrx, oracle, mode, seconds):
+    """The envelope beyond the committed fixture, in every mode (IF rates 240 / 288 / 240 / 320 kHz): a synthetic stream of
+    `seconds`, fed in calls of 60 reference blocks, against the oracle for the whole stream: per 1 s window the left and right
+    channels stay within ENVELOPE_FACTOR * ulp(trigArg(t)) (measured 0.016 .. 0.042: profiles/round2/stereo_error_vs_time_long.txt,
+    stereo_error_vs_time_modes123.txt), without PLL repairs."""
+    p = oracle.mode_params(mode, 101, 101, 101)
+    nblk = int(seconds * p.rf_Fs / (p.block_bytes // 2)) // 60 * 60
+    iq = oracle.synth_fm_u8(p.block_bytes // 2 * nblk, rf_Fs=p.rf_Fs, seed=0x3D74)
+    po, pl = oracle.pipeline(mode, 2), fmrx.Pipeline(mode, 2, max_block_bytes=60 * p.block_bytes)
+    ref = [po.process(iq[o:o + p.block_bytes]) for o in range(0, len(iq), p.block_bytes)]
+    out = [pl.process(iq[o:o + 60 * p.block_bytes]) for o in range(0, len(iq), 60 * p.block_bytes)]
+    if_Fs = p.rf_Fs / p.rf_decim
+    for k in ("audio_l", "audio_r"):
+        a, b = np.concatenate([r[k] for r in out]), np.concatenate([r[k] for r in ref])
+        win = int(round(len(b) / (len(iq) / 2 / p.rf_Fs)))             # audio samples per second
+        env = stereo_error_envelope(a, b, win)
+        t_end = np.arange(1, len(env) + 1, dtype=np.float64)
+        u = trig_arg_ulp(t_end, if_Fs=if_Fs)
+        print(f"mode {mode} {k}: error per 1 s window in ulp(trigArg):", " ".join(f"{e / x:.3f}" for e, x in zip(env, u)))
+        assert (env <= np.maximum(AUDIO_ABS_RMS, ENVELOPE_FACTOR * u)).all(), (mode, k, env / u)
+    assert pl.pll_diagnostics()[0] == 0
+
+
 def test_stereo_parallel_pll_late_in_a_stream(fmrx, oracle):
     """35 s into a stream the float32 trigArg resolves 0.5 rad: the linear-system start of the PLL's lanes (which treats
     that grid as a perturbation) hands over to long warm-ups of true steps (kernels_pll.hip: k_fm_pll_parallel).  Nine
