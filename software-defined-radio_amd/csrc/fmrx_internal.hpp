@@ -193,23 +193,8 @@ struct BpfPairPlan {
     DevBuf<float> h_st, h_car;  // plain taps (generic path)
 };
 int bpf_pair_plan_init(BpfPairPlan &pl, const float *h_stereo, const float *h_carrier, int taps);
-// Chunk records of the parallel PLL's linear-system start (kernels_pll.hip: DESIGN 4.5).  Their producer is either
-// pll_lti_chunks_kernel (groups of 64 chunks) or the band-pass pair kernel itself, which has the PLL's input in registers as it
-// writes it (groups of 32 chunks = one of its workgroups: one launch less).  All sums are in half turns x 2 = sign changes / 2.
-struct PllLtiRecords {
-    double *rec = nullptr;       // per 64-sample chunk: {R_phi, R_iota (zero-state response to its own staircase), climb in front of it inside
-                                 //   its group incl. the boundaries between the group's chunks, its own inner climb}
-    double *wgtot = nullptr;     // per group: its chunks' inner climbs + the boundaries between them
-    unsigned *wgsign = nullptr;  // per group: bit 0 = its first sample > 0, bit 1 = its last sample > 0
-    int wg_chunks = 0;           // chunks per group
-    double a00 = 0.0, a10 = 0.0, b0 = 0.0, b1 = 0.0, f = 0.0;   // s' = A s + B x with a01 = a11 = 1; f = freq / Fs (revolutions per sample)
-};
-// where the records of a block of n_total samples live in the PLL scratch (pll_parallel_scratch_floats(n_total) floats), and the loop's
-// coefficients: the same for whoever produces and whoever reads them
-PllLtiRecords pll_lti_records(float *d_scratch, size_t n_total, int wg_chunks, float freq, float Fs, float normBandwidth);
-// lti (optional): also leave the chunk records of d_car (the PLL's input) behind; *lti_done says whether this launch did
 int bpf_pair_launch(const BpfPairPlan &pl, const float *d_x, size_t n, float *d_st, float *d_car, hipStream_t stream,
-                    bool force_generic, const PllLtiRecords *lti = nullptr, bool *lti_done = nullptr);
+                    bool force_generic);
 
 // everything behind the PLL of modes 0/1 in one kernel: mixer, both audio FIRs (mono branch on the all-passed
 // discriminator output, stereo branch on the mixer output), L/R combine, PCM (kernels_stereo.hip)
@@ -261,8 +246,7 @@ constexpr float kPllTolPhase = 1e-2f, kPllTolInteg = 1e-4f;
 size_t pll_parallel_scratch_floats(size_t n);
 int k_fm_pll_parallel(const float *d_in, size_t n, float *d_out, float *d_state, float freq, float Fs, float ncoScale,
                       float phaseAdjust, float normBandwidth, float *d_scratch, const Options &o, hipStream_t s,
-                      double off_hint = -1.0,    // off_hint: IF samples of the stream in front of this call (the state's trigOffset), < 0 = unknown
-                      const PllLtiRecords *pre = nullptr, long pre_chunk0 = 0);   // records already produced for a block of which d_in is chunk pre_chunk0 onwards
+                      double off_hint = -1.0);   // off_hint: IF samples of the stream in front of this call (the state's trigOffset), < 0 = unknown
 int k_mix(const float *d_bpf, const float *d_pll, size_t n, float *d_mix, hipStream_t s);
 int k_combine(const float *d_st, const float *d_mono, size_t n, float *d_l, float *d_r, hipStream_t s);
 int k_upsample(const float *d_x, size_t n, float *d_xu, int up, hipStream_t s);

@@ -214,101 +214,70 @@ __global__ void nco_out_kernel(float *__restrict__ out, size_t n, PllCoef c)
 // pilot's (a glitch: two sign changes within a sample or two) breaks the staircase rule; the lanes' ends then do not
 // meet their successors' starts and pll_repair_kernel walks those stretches serially, as before.
 constexpr int kLtiTerms = 20;          // (A^64)^20 ~ 5e-8: what is dropped of the state 1280 samples back
-// One chunk's part of the records (PllLtiRecords, fmrx_internal.hpp) from its 64 signs: bit j of `signs` = sample j > 0, `valid`
-// = how many of them exist (the block's last chunk may be short: the missing ones repeat the last sign).  Returns the inner
-// climb (sign changes between the chunk's own samples, / 2).
-__device__ __forceinline__ double lti_chunk_response(unsigned long long signs, int valid, const PllLtiRecords &R, double &phi,
-                                                     double &iota, bool &first, bool &last)
+struct LtiMat {
+    double a00, a01, a10, a11, b0, b1;   // s' = A s + B x, s = (phi, iota)
+};
+__device__ __forceinline__ LtiMat lti_of(const PllCoef &c)
 {
-    phi = 0.0;
-    iota = 0.0;
-    double dT = 0.0;
-    bool pos = signs & 1ull;
-    first = pos;
-#pragma unroll 8
-    for (int j = 0; j < kLtiChunk; j++) {
-        const double x = dT - R.f * j;
-        const double p = R.a00 * phi + iota + R.b0 * x;
-        iota = R.a10 * phi + iota + R.b1 * x;
-        phi = p;
-        const bool pn = j + 1 < valid ? ((signs >> (j + 1)) & 1ull) != 0 : pos;
-        if (j + 1 < kLtiChunk) dT += pn != pos ? 0.5 : 0.0;
-        pos = pn;
-    }
-    last = pos;
-    return dT;
+    const double Kp = c.Kp, Ki = c.Ki;
+    return LtiMat{1.0 - Kp - Ki, 1.0, -Ki, 1.0, Kp + Ki, Ki};
+}
+__device__ __forceinline__ void lti_step(const LtiMat &m, double &phi, double &iota, double x)
+{
+    const double p = m.a00 * phi + m.a01 * iota + m.b0 * x;
+    iota = m.a10 * phi + m.a11 * iota + m.b1 * x;
+    phi = p;
 }
 
-// One group's records from its chunks' responses: lane c of the wave holds chunk c of the group (`chunks` of them, inactive lanes
-// pass inner = 0 and first = last = the previous lane's last).  Writes rec[.. + 2], rec[.. + 3], wgtot, wgsign.
-__device__ __forceinline__ void lti_group_records(const PllLtiRecords &R, long group, long chunk, bool have, double phi, double iota,
-                                                  double inner, bool first, bool last, int lane, int group_lanes)
-{
-    // boundary INTO this chunk from the previous chunk of the group
-    const int prev_last = __shfl_up(static_cast<int>(last), 1, 64);
-    const double bnd = (lane > 0 && have && (prev_last != 0) != first) ? 0.5 : 0.0;
-    double incl = inner + bnd;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const double o = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += o;
-    }
-    if (have) {
-        R.rec[4 * chunk + 0] = phi;
-        R.rec[4 * chunk + 1] = iota;
-        R.rec[4 * chunk + 2] = incl - inner;               // climb in front of the chunk inside its group, boundary into it included
-        R.rec[4 * chunk + 3] = inner;
-    }
-    // the group's total and end signs: from its last lane (inactive lanes carried the values along)
-    const int first0 = __shfl(static_cast<int>(first), 0, 64);
-    if (lane == group_lanes - 1) {
-        R.wgtot[group] = incl;
-        R.wgsign[group] = static_cast<unsigned>(first0 != 0) | (static_cast<unsigned>(last) << 1);
-    }
-}
-
-// the stand-alone producer: one thread per chunk, groups of 64 chunks (one wave); a lane reads its chunk as 16 aligned 16-byte groups
-__global__ __launch_bounds__(64) void pll_lti_chunks_kernel(const float *__restrict__ in, long n, long nchunk, PllLtiRecords R)
+// rec[4 i ..] = {R_phi, R_iota: zero-state response of chunk i to its own staircase; the climb of the chunks in front of
+// it inside its workgroup of 64 chunks; its own climb (sign changes inside it and into the next chunk's first sample, / 2)};
+// wgtot[w] = climb of workgroup w's 64 chunks.  A lane reads its chunk as 16 aligned 16-byte groups.
+__global__ __launch_bounds__(64) void pll_lti_chunks_kernel(const float *__restrict__ in, long n, PllCoef c, long nchunk,
+                                                            double *__restrict__ rec, double *__restrict__ wgtot)
 {
     typedef float f4 __attribute__((ext_vector_type(4)));
-    const int lane = threadIdx.x;
-    const long i = static_cast<long>(blockIdx.x) * 64 + lane;
-    const bool have = i < nchunk;
-    unsigned long long signs = 0;
-    int valid = 0;
-    if (have) {
+    const long i = static_cast<long>(blockIdx.x) * 64 + threadIdx.x;
+    const LtiMat m = lti_of(c);
+    const double f = c.w * 0.15915494309189533577;
+    double phi = 0.0, iota = 0.0, dT = 0.0;
+    if (i < nchunk) {
         const long k0 = i * kLtiChunk;
         const f4 *in4 = reinterpret_cast<const f4 *>(in + k0);
         const long last4 = (n + 3) / 4 + 1 - k0 / 4;                   // groups of this chunk that are safe to read (host contract)
+        f4 v[kLtiChunk / 4];
 #pragma unroll
-        for (int q = 0; q < kLtiChunk / 4; q++) {
-            const f4 v = in4[q < last4 ? q : last4];
+        for (int q = 0; q < kLtiChunk / 4; q++) v[q] = in4[q < last4 ? q : last4];
+        const float nxt = k0 + kLtiChunk < n ? in[k0 + kLtiChunk] : 0.0f;
+        bool pos = v[0][0] > 0.0f;
 #pragma unroll
-            for (int e = 0; e < 4; e++) signs |= static_cast<unsigned long long>(v[e] > 0.0f) << (4 * q + e);
+        for (int j = 0; j < kLtiChunk; j++) {
+            lti_step(m, phi, iota, dT - f * j);
+            const long k = k0 + j + 1;
+            const float vn = j + 1 < kLtiChunk ? v[(j + 1) / 4][(j + 1) % 4] : nxt;
+            const bool pn = k < n ? vn > 0.0f : pos;
+            dT += pn != pos ? 0.5 : 0.0;
+            pos = pn;
         }
-        valid = n - k0 < kLtiChunk ? static_cast<int>(n - k0) : kLtiChunk;
     }
-    double phi = 0.0, iota = 0.0, inner = 0.0;
-    bool first = false, last = false;
-    if (have) inner = lti_chunk_response(signs, valid, R, phi, iota, first, last);
-    // inactive lanes: first = last = the nearest active lane's last sign, so that no boundary is counted and the group's end sign is right
-    {
-        int l = static_cast<int>(last), h = static_cast<int>(have);
+    // exclusive prefix of the climbs over the workgroup's 64 chunks (one wave)
+    double incl = dT;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int ol = __shfl_up(l, d, 64), oh = __shfl_up(h, d, 64);
-            if (lane >= d && !h) {
-                l = ol;
-                h = oh;
-            }
-        }
-        if (!have) first = last = l != 0;
+    for (int d = 1; d < 64; d <<= 1) {
+        const double o = __shfl_up(incl, d, 64);
+        if (static_cast<int>(threadIdx.x) >= d) incl += o;
     }
-    lti_group_records(R, blockIdx.x, i, have, phi, iota, inner, first, last, lane, 64);
+    if (i < nchunk) {
+        rec[4 * i + 0] = phi;
+        rec[4 * i + 1] = iota;
+        rec[4 * i + 2] = incl - dT;
+        rec[4 * i + 3] = dT;
+    }
+    if (threadIdx.x == 63) wgtot[blockIdx.x] = incl;
 }
 
-// (integ, phase) the locked loop has in front of a chunk, from the records: Horner over the kLtiTerms chunks behind it, oldest
-// first; near the start of the PLL's own input the true initial state takes the place of what was dropped.
+// (integ, phase) the locked loop has in front of sample 64 i, from the chunk records: Horner over the kLtiTerms chunks
+// behind it, oldest first; near the block start the true initial state takes the place of what was dropped.  `wg_climb`
+// = climb of all chunks in front of workgroup i / 64 (the caller sums wgtot once per wave).
 struct LtiStart {
     double q00, q01, q10, q11, g0, g1;      // Q = A^64; G = one chunk's response to the constant 1
     double f, phi0, iota0, off0, T0;
@@ -328,40 +297,28 @@ __device__ __forceinline__ LtiStart lti_start_setup(const float *in, const float
     L.T0 = in[0] > 0.0f ? rint(th0) : rint(th0 - 0.5) + 0.5;
     return L;
 }
-// half the sign changes between group u - 1's last sample and group u's first
-__device__ __forceinline__ double lti_group_boundary(const PllLtiRecords &R, long u)
+// wg_climb0 = climb of all chunks in front of workgroup wg0 (of 64 chunks); chunk i lies in wg0 or wg0 + 1
+__device__ __forceinline__ void lti_start_state(const LtiStart &L, const double *__restrict__ rec, const double *__restrict__ wgtot,
+                                                long i, long wg0, double wg_climb0, float &integ, float &phase)
 {
-    return u > 0 && ((R.wgsign[u - 1] >> 1) & 1u) != (R.wgsign[u] & 1u) ? 0.5 : 0.0;
-}
-// i = chunk index inside the PLL's own input (its chunk 0 = record chunk0, whose climb is climb0); wg0 / base0 = the group of
-// the wave's first lane and the climb in front of that group (boundary into it included): chunk i and the kLtiTerms behind it
-// lie in groups wg0 - 1 .. wg0 + 2
-__device__ __forceinline__ void lti_start_state(const LtiStart &L, const PllLtiRecords &R, long i, long chunk0, double climb0,
-                                                long wg0, double base0, float &integ, float &phase)
-{
-    double wbase[4];                                          // climb in front of groups wg0 - 1, wg0, wg0 + 1, wg0 + 2
-    wbase[1] = base0;
-    wbase[0] = wg0 > 0 ? base0 - lti_group_boundary(R, wg0) - R.wgtot[wg0 - 1] : 0.0;
-    wbase[2] = base0 + R.wgtot[wg0] + lti_group_boundary(R, wg0 + 1);
-    wbase[3] = wbase[2] + R.wgtot[wg0 + 1] + lti_group_boundary(R, wg0 + 2);
+    const double tot0 = wgtot[wg0], totm = wg0 > 0 ? wgtot[wg0 - 1] : 0.0;
     double r0[kLtiTerms], r1[kLtiTerms];
 #pragma unroll
-    for (int t = 0; t < kLtiTerms; t++) {                     // term t: chunk i - (kLtiTerms - t), oldest first
+    for (int t = 0; t < kLtiTerms; t++) {                     // term t: chunk j = i - (kLtiTerms - t), oldest first
         const long jj = i - (kLtiTerms - t);
-        const long jl = jj > 0 ? jj : 0;                      // inside the PLL's input
-        const long j = jl + chunk0;                           // record index
-        const long q = j / R.wg_chunks - (wg0 - 1);
-        const double wb = q <= 0 ? wbase[0] : (q == 1 ? wbase[1] : (q == 2 ? wbase[2] : wbase[3]));
-        // T at the start of the chunk, then C = T - f off - phi0
-        const double base = (L.T0 + (wb + R.rec[4 * j + 2] - climb0)) - L.f * (L.off0 + static_cast<double>(jl * kLtiChunk)) - L.phi0;
-        r0[t] = R.rec[4 * j + 0] + base * L.g0;
-        r1[t] = R.rec[4 * j + 1] + base * L.g1;
+        const long j = jj > 0 ? jj : 0;
+        const long wj = j / 64;
+        // T at the start of chunk j, from its workgroup's base (wg0 - 1, wg0 or wg0 + 1) and its prefix inside it
+        const double wbase = wj == wg0 ? wg_climb0 : (wj > wg0 ? wg_climb0 + tot0 : wg_climb0 - totm);
+        const double base = (L.T0 + wbase + rec[4 * j + 2]) - L.f * (L.off0 + static_cast<double>(j * kLtiChunk)) - L.phi0;
+        r0[t] = rec[4 * j + 0] + base * L.g0;
+        r1[t] = rec[4 * j + 1] + base * L.g1;
     }
     double p = 0.0, q = 0.0;
 #pragma unroll
     for (int t = 0; t < kLtiTerms; t++) {
         const long jj = i - (kLtiTerms - t);
-        if (jj == 0) {                                        // the true initial state, in deviations from (phi0, 0)
+        if (jj == 0) {                                        // the block's true initial state, in deviations from (phi0, 0)
             p = 0.0;
             q = L.iota0;
         }
@@ -418,24 +375,24 @@ __device__ __forceinline__ float pll_integ_tol(float base, const float *state, l
 // samples instead of the 768 it takes to forget a guess that ignores the ripple).  P = 0: no alignment.
 __global__ void pll_segments_kernel(const float *__restrict__ in, long n, float *__restrict__ out,
                                     const float *__restrict__ state, PllCoef c, int L, int W, int P, long nseg,
-                                    float *__restrict__ seg, float *hdr, PllLtiRecords lti, long lti_chunk0,
-                                    unsigned long long *__restrict__ badmask, float tol_phase_base, float tol_integ_base)
+                                    float *__restrict__ seg, float *hdr, const double *__restrict__ lti_rec,
+                                    const double *__restrict__ lti_wgtot, unsigned long long *__restrict__ badmask,
+                                    float tol_phase_base, float tol_integ_base)
 {
     const long sg = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
-    // linear-system start: the climb in front of the group of chunks this wave's first lane starts in, summed by the whole wave
-    // (its 64 lanes start in that group or the two behind it), and the climb in front of the PLL's own first chunk
+    // linear-system start: the climb of the chunk workgroups in front of the one this wave's first lane starts in, summed by
+    // the whole wave (its 64 lanes start in that workgroup of 64 chunks or the next one)
     long lti_wg0 = 0;
-    double lti_base0 = 0.0, lti_climb0 = 0.0;
-    if (lti.rec) {
+    double lti_climb0 = 0.0;
+    if (lti_rec) {
         const long a0 = static_cast<long>(blockIdx.x) * blockDim.x * L;
         const long k0 = a0 > W ? a0 - W : 0;
-        lti_wg0 = (k0 / kLtiChunk + lti_chunk0) / lti.wg_chunks;
+        lti_wg0 = (k0 / kLtiChunk) / 64;
         double part = 0.0;
-        for (long u = threadIdx.x; u < lti_wg0; u += 64) part += lti.wgtot[u] + lti_group_boundary(lti, u + 1);
+        for (long u = threadIdx.x; u < lti_wg0; u += 64) part += lti_wgtot[u];
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
-        lti_base0 = part;
-        lti_climb0 = lti.rec[4 * lti_chunk0 + 2];              // host contract: lti_chunk0 lies in group 0
+        lti_climb0 = part;
     }
     if (sg >= nseg) return;
     const long a = sg * L;
@@ -448,10 +405,10 @@ __global__ void pll_segments_kernel(const float *__restrict__ in, long n, float 
         if (P > 0) k -= k % P;
     }
     if (k > 0) {
-        if (lti.rec) {
+        if (lti_rec) {
             // the linear system's state in front of sample k (a multiple of 64: host contract)
             const LtiStart Ls = lti_start_setup(in, state, c);
-            lti_start_state(Ls, lti, k / kLtiChunk, lti_chunk0, lti_climb0, lti_wg0, lti_base0, s.integ, s.phase);
+            lti_start_state(Ls, lti_rec, lti_wgtot, k / kLtiChunk, lti_wg0, lti_climb0, s.integ, s.phase);
         } else {
             // hdr[5..7] = {phase at the start of the previous call, its length, valid}: the drift
             const float slope = hdr[7] != 0.0f ? (s0.phase - hdr[5]) / hdr[6] : 0.0f;
@@ -706,39 +663,15 @@ int k_libm_eval(int fn, const float *d_a, const float *d_b, size_t n, float *d_o
     return FMRX_OK;
 }
 
-// scratch: [0..7] header, per-segment records + mismatch mask (sized for the shortest segments), then the linear-system records
-static size_t pll_lti_offset(size_t n_total)
-{
-    const size_t nseg = n_total / kPllSegmentMin + 3;
-    size_t off = 8 + nseg * 16 + 2 * (nseg / 64 + 2);
-    return off + (off & 1);                                    // doubles
-}
 size_t pll_parallel_scratch_floats(size_t n)
 {
-    const size_t nchunk = n / kLtiChunk + 2, ngroup = nchunk / 32 + 3;
-    return pll_lti_offset(n) + nchunk * 8 + ngroup * 2 + ngroup + 2;
-}
-PllLtiRecords pll_lti_records(float *d_scratch, size_t n_total, int wg_chunks, float freq, float Fs, float normBandwidth)
-{
-    const PllCoef c = make_coef(freq, Fs, 1.0f, 0.0f, normBandwidth);
-    const size_t nchunk = n_total / kLtiChunk + 2, ngroup = nchunk / 32 + 3;
-    PllLtiRecords R;
-    R.rec = reinterpret_cast<double *>(d_scratch + pll_lti_offset(n_total));
-    R.wgtot = R.rec + nchunk * 4;
-    R.wgsign = reinterpret_cast<unsigned *>(R.wgtot + ngroup);
-    R.wg_chunks = wg_chunks;
-    const double Kp = c.Kp, Ki = c.Ki;
-    R.a00 = 1.0 - Kp - Ki;
-    R.a10 = -Ki;
-    R.b0 = Kp + Ki;
-    R.b1 = Ki;
-    R.f = c.w * 0.15915494309189533577;
-    return R;
+    const size_t nseg = n / kPllSegmentMin + 2;
+    const size_t nchunk = n / kLtiChunk + 2;
+    return 8 + nseg * 16 + 2 * (nseg / 64 + 2) + 2 + (nchunk + 2) * 8 + 2 * (nchunk / 64 + 2);   // + chunk records (4 doubles), workgroup totals
 }
 
 int k_fm_pll_parallel(const float *d_in, size_t n, float *d_out, float *d_state, float freq, float Fs, float ncoScale,
-                      float phaseAdjust, float normBandwidth, float *d_scratch, const Options &o, hipStream_t s, double off_hint,
-                      const PllLtiRecords *pre, long pre_chunk0)
+                      float phaseAdjust, float normBandwidth, float *d_scratch, const Options &o, hipStream_t s, double off_hint)
 {
     int L = kPllSegment, W = kPllWarmup;
     if (o.pll_warmup >= 0 && o.pll_warmup <= 65536) W = o.pll_warmup / 4 * 4;                    // tuning: warm-up samples per lane
@@ -775,23 +708,23 @@ int k_fm_pll_parallel(const float *d_in, size_t n, float *d_out, float *d_state,
     float *seg = d_scratch + 8;
     unsigned long long *badmask = reinterpret_cast<unsigned long long *>(seg + (nseg + 1) * 16);
     const unsigned grid = static_cast<unsigned>((nseg + 63) / 64);
-    PllLtiRecords rec;                                          // rec.rec == nullptr: lanes start the first way
-    long chunk0 = 0;
+    const double *lti_rec = nullptr, *lti_wgtot = nullptr;
     if (lti) {
         c.integ_tol_ulps = kPllIntegTolUlpsLti;
-        if (pre && pre->rec && pre_chunk0 >= 0 && pre_chunk0 < pre->wg_chunks) {
-            rec = *pre;                                            // left behind by the producer of d_in (bpf_pair_kernel)
-            chunk0 = pre_chunk0;
-        } else {
-            const long nchunk = static_cast<long>(n / kLtiChunk) + 1;
-            rec = pll_lti_records(d_scratch, n, 64, freq, Fs, normBandwidth);
-            hipLaunchKernelGGL(pll_lti_chunks_kernel, dim3(static_cast<unsigned>((nchunk + 63) / 64)), dim3(64), 0, s, d_in,
-                               static_cast<long>(n), nchunk, rec);
-            FMRX_LAUNCH_CHECK("pll_lti_chunks");
-        }
+        const long nchunk = static_cast<long>(n / kLtiChunk) + 1;
+        const size_t mask_floats = 2 * (static_cast<size_t>(nseg) / 64 + 2);
+        size_t off = 8 + (static_cast<size_t>(nseg) + 1) * 16 + mask_floats;
+        off += off & 1;                                            // doubles
+        double *rec = reinterpret_cast<double *>(d_scratch + off);
+        double *wgtot = rec + 4 * (nchunk + 1);
+        hipLaunchKernelGGL(pll_lti_chunks_kernel, dim3(static_cast<unsigned>((nchunk + 63) / 64)), dim3(64), 0, s, d_in,
+                           static_cast<long>(n), c, nchunk, rec, wgtot);
+        FMRX_LAUNCH_CHECK("pll_lti_chunks");
+        lti_rec = rec;
+        lti_wgtot = wgtot;
     }
     hipLaunchKernelGGL(pll_segments_kernel, dim3(grid), dim3(64), 0, s, d_in, static_cast<long>(n), d_out, d_state, c, L, W, P,
-                       nseg, seg, d_scratch, rec, chunk0, badmask, kPllTolPhase, kPllTolInteg);
+                       nseg, seg, d_scratch, lti_rec, lti_wgtot, badmask, kPllTolPhase, kPllTolInteg);
     FMRX_LAUNCH_CHECK("pll_segments");
     hipLaunchKernelGGL(pll_repair_kernel, dim3(1), dim3(kRepairThreads), 0, s, d_in, static_cast<long>(n), d_out, d_state, c, L, nseg, seg,
                        badmask, kPllTolPhase, kPllTolInteg, n_repaired, d_scratch);

@@ -254,10 +254,8 @@ int bpf_pair_plan_init(BpfPairPlan &pl, const float *h_stereo, const float *h_ca
 
 // d_x: block start (16-byte aligned), taps-1+3 samples of history in front
 int bpf_pair_launch(const BpfPairPlan &pl, const float *d_x, size_t n, float *d_st, float *d_car, hipStream_t stream,
-                    bool force_generic, const PllLtiRecords *lti, bool *lti_done)
+                    bool force_generic)
 {
-    if (lti_done) *lti_done = false;
-    (void)lti;
     if (n == 0) return FMRX_OK;
     if (pl.fast && !force_generic && reinterpret_cast<uintptr_t>(d_x) % 16 == 0 && reinterpret_cast<uintptr_t>(d_st) % 16 == 0 &&
         reinterpret_cast<uintptr_t>(d_car) % 16 == 0) {
