@@ -389,7 +389,13 @@ __global__ void pll_segments_kernel(const float *__restrict__ in, long n, float 
         const long k0 = a0 > W ? a0 - W : 0;
         lti_wg0 = (k0 / kLtiChunk) / 64;
         double part = 0.0;
-        for (long u = threadIdx.x; u < lti_wg0; u += 64) part += lti_wgtot[u];
+        // the first 512 totals as 8 loads in flight per lane (a loop of dependent iterations pays a memory round trip each)
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const long u = threadIdx.x + 64 * r;
+            part += u < lti_wg0 ? lti_wgtot[u] : 0.0;
+        }
+        for (long u = threadIdx.x + 512; u < lti_wg0; u += 64) part += lti_wgtot[u];
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
         lti_climb0 = part;

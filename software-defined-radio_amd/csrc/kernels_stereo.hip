@@ -198,7 +198,7 @@ __global__ __launch_bounds__(NT) void stereo_out_kernel(const float *__restrict_
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = (f2){0.0f, 0.0f};
     const f2 *w0 = win + D * t + (T - 1);
-#pragma unroll 4
+#pragma unroll 8
     for (int n = 0; n < T; n++) {
         const float hn = h[n];                             // wave-uniform: scalar load
 #pragma unroll
