@@ -380,22 +380,23 @@ __global__ void pll_segments_kernel(const float *__restrict__ in, long n, float 
                                     float tol_phase_base, float tol_integ_base)
 {
     const long sg = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;                        // a wave = 64 consecutive segments = one word of the mismatch mask
     // linear-system start: the climb of the chunk workgroups in front of the one this wave's first lane starts in, summed by
     // the whole wave (its 64 lanes start in that workgroup of 64 chunks or the next one)
     long lti_wg0 = 0;
     double lti_climb0 = 0.0;
     if (lti_rec) {
-        const long a0 = static_cast<long>(blockIdx.x) * blockDim.x * L;
+        const long a0 = (sg - lane) * L;                       // the wave's first lane
         const long k0 = a0 > W ? a0 - W : 0;
         lti_wg0 = (k0 / kLtiChunk) / 64;
         double part = 0.0;
         // the first 512 totals as 8 loads in flight per lane (a loop of dependent iterations pays a memory round trip each)
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const long u = threadIdx.x + 64 * r;
+            const long u = lane + 64 * r;
             part += u < lti_wg0 ? lti_wgtot[u] : 0.0;
         }
-        for (long u = threadIdx.x + 512; u < lti_wg0; u += 64) part += lti_wgtot[u];
+        for (long u = lane + 512; u < lti_wg0; u += 64) part += lti_wgtot[u];
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
         lti_climb0 = part;
@@ -497,7 +498,7 @@ __global__ void pll_segments_kernel(const float *__restrict__ in, long n, float 
         const float pe_integ = __shfl_up(s.integ, 1, 64), pe_phase = __shfl_up(s.phase, 1, 64);
         bool bad = false;
         float dp = 0.0f, di = 0.0f;
-        if (threadIdx.x > 0) {
+        if (lane > 0) {
             di = fabsf(start_integ - pe_integ);
             dp = pll_phase_dist(start_phase, pe_phase);
             bad = !(dp <= tol_phase && di <= tol_integ);
@@ -508,7 +509,7 @@ __global__ void pll_segments_kernel(const float *__restrict__ in, long n, float 
             dp = fmaxf(dp, __shfl_xor(dp, o, 64));
             di = fmaxf(di, __shfl_xor(di, o, 64));
         }
-        if (threadIdx.x == 0) {
+        if (lane == 0) {
             unsigned *diag = reinterpret_cast<unsigned *>(hdr);
             badmask[sg / 64] = m;
             if (m) hdr[1] = 1.0f;                              // "some segment needs repair"; cleared by pll_repair_kernel
@@ -713,7 +714,8 @@ int k_fm_pll_parallel(const float *d_in, size_t n, float *d_out, float *d_state,
     unsigned *n_repaired = reinterpret_cast<unsigned *>(d_scratch + 2);
     float *seg = d_scratch + 8;
     unsigned long long *badmask = reinterpret_cast<unsigned long long *>(seg + (nseg + 1) * 16);
-    const unsigned grid = static_cast<unsigned>((nseg + 63) / 64);
+    constexpr int kSegThreads = 64;                             // lanes per workgroup of pll_segments_kernel: one wave (256 was measured: 23.1 vs 21.2 us)
+    const unsigned grid = static_cast<unsigned>((nseg + kSegThreads - 1) / kSegThreads);
     const double *lti_rec = nullptr, *lti_wgtot = nullptr;
     if (lti) {
         c.integ_tol_ulps = kPllIntegTolUlpsLti;
@@ -729,7 +731,7 @@ int k_fm_pll_parallel(const float *d_in, size_t n, float *d_out, float *d_state,
         lti_rec = rec;
         lti_wgtot = wgtot;
     }
-    hipLaunchKernelGGL(pll_segments_kernel, dim3(grid), dim3(64), 0, s, d_in, static_cast<long>(n), d_out, d_state, c, L, W, P,
+    hipLaunchKernelGGL(pll_segments_kernel, dim3(grid), dim3(kSegThreads), 0, s, d_in, static_cast<long>(n), d_out, d_state, c, L, W, P,
                        nseg, seg, d_scratch, lti_rec, lti_wgtot, badmask, kPllTolPhase, kPllTolInteg);
     FMRX_LAUNCH_CHECK("pll_segments");
     hipLaunchKernelGGL(pll_repair_kernel, dim3(1), dim3(kRepairThreads), 0, s, d_in, static_cast<long>(n), d_out, d_state, c, L, nseg, seg,
