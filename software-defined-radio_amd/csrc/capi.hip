@@ -58,6 +58,7 @@ bool option_ref(Options &o, const char *name, long **as_long, int **as_int)
     else if (n == "pll_start") *as_int = &o.pll_start;
     else if (n == "pll_align") *as_int = &o.pll_align;
     else if (n == "pll_mode") *as_int = &o.pll_mode;
+    else if (n == "resample_chains") *as_int = &o.resample_chains;
     else if (n == "fused_tune") *as_int = &o.fused_tune;
     else if (n == "fe_mfma_tune") *as_int = &o.fe_mfma_tune;
     else return false;
@@ -73,6 +74,7 @@ Options &default_options()
         if (const char *e = std::getenv("FMRX_FUSED_MIN_AUDIO")) d.fused_min_audio = std::atol(e);
         if (std::getenv("FMRX_RESAMPLE_L2")) d.resample_l2 = 1;
         if (const char *e = std::getenv("FMRX_RESAMPLE_EXACT")) d.resample_exact = std::atoi(e);
+        if (const char *e = std::getenv("FMRX_RESAMPLE_CHAINS")) d.resample_chains = std::atoi(e);
         if (const char *e = std::getenv("FMRX_FE_WGS_PER_CU")) d.fe_wgs_per_cu = std::atoi(e);
         if (const char *e = std::getenv("FMRX_PLL_WARMUP")) d.pll_warmup = std::atoi(e);
         if (const char *e = std::getenv("FMRX_PLL_SEGMENT")) d.pll_segment = std::atoi(e);

@@ -63,4 +63,17 @@ __device__ __forceinline__ int16_t pcm_pack(float a, int wrap)
     return static_cast<int16_t>(s);
 }
 
+// the same value without a branch (straight-line epilogues): out of range or NaN -> 0 either way under wrap (the low 16 bits of
+// cvttss2si's 0x80000000); v_cvt_i32_f32 itself saturates, so it is only used in range
+__device__ __forceinline__ int16_t pcm_pack_flat(float a, int wrap)
+{
+    const float s = a * 16384.0f;
+    const float c = fminf(fmaxf(s, -32768.0f), 32767.0f);                    // saturating form (NaN -> -32768 here, 0 below)
+    const bool keep = wrap ? (s < 2147483648.0f && s >= -2147483648.0f) : a == a;   // false for NaN in both forms
+    const float arg = wrap ? s : c;
+    int v;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(v) : "v"(arg));
+    return static_cast<int16_t>(static_cast<uint16_t>(keep ? static_cast<uint32_t>(v) : 0u));
+}
+
 }  // namespace fmrx

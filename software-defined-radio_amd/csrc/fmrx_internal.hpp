@@ -47,6 +47,8 @@ struct Options {
     int resample_l2 = 0;           // "resample_l2" / FMRX_RESAMPLE_L2: 1 = L2-table resampler kernel even for large calls
     int resample_exact = 0;        // "resample_exact" / FMRX_RESAMPLE_EXACT: 1 = the pipeline's resampler keeps the reference's rounding sequence
                                    //   (the bit-exact LDS-table kernel instead of the matrix-core one)
+    int resample_chains = 0;       // "resample_chains" / FMRX_RESAMPLE_CHAINS: workgroups per XCD and tile group of the matrix-core resampler
+                                   //   (0 = as many as are resident at once); A/B knob
     int fe_wgs_per_cu = 0;         // "fe_wgs_per_cu" / FMRX_FE_WGS_PER_CU: cap on resident workgroups per CU of the front-end kernels (0 = auto)
     int pll_warmup = -1;           // "pll_warmup" / FMRX_PLL_WARMUP: warm-up samples per lane of the parallel PLL (-1 = built-in)
     int pll_segment = -1;          // "pll_segment" / FMRX_PLL_SEGMENT: samples per lane (-1 = built-in)
@@ -175,14 +177,20 @@ struct ResamplePlan {
     // matrix-core kernel (pipeline path): tap image [tile][lane][K-step], K index 0 of every tile, tile groups
     bool mfma = false;
     int mfma_ks4 = 0, mfma_ngroups = 0, mfma_pieces = 0;
+    bool mfma_reach_ok = false;   // piece staging stays within kResampleFront / kResampleBack of the block (else: element staging)
+    mutable int mfma_wgs_per_cu[2] = {0, 0};   // resident workgroups per CU of the kernel instance in use (piece / element staging), asked once
     DevBuf<float> mfma_img;
     DevBuf<int> mfma_top, mfma_groups;   // per tile: K index 0's input offset; per group: m0, m1, lo, pieces
 };
 int resample_plan_init(ResamplePlan &pl, const float *h, int taps, int decim, int upsamp);
 // exact: only the kernels that keep the reference's rounding sequence (the primitive's contract)
 // d_pcm: also pack s16 PCM (d_y may then be null where resample_mfma_available(): that kernel writes either or both)
+// margins: the caller vouches for finite, readable samples kResampleFront floats in front of d_x - delay and kResampleBack
+// behind its n_in samples (the matrix-core kernel then stages every block alike; only taps that are zero meet those samples)
+constexpr int kResampleFront = 256, kResampleBack = 1024;
 int resample_launch(const ResamplePlan &pl, const float *d_x, size_t n_in, int delay, float *d_y, const Options &o,
-                    hipStream_t stream, bool force_generic, bool exact = false, int16_t *d_pcm = nullptr, int wrap = 0);
+                    hipStream_t stream, bool force_generic, bool exact = false, int16_t *d_pcm = nullptr, int wrap = 0,
+                    bool margins = false);
 bool resample_mfma_available(const ResamplePlan &pl, const float *d_x, size_t n_in, int delay, const Options &o);
 
 // ---- stereo band-pass pair (kernels_stereo.hip) ------------------------------------

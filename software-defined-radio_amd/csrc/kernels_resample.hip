@@ -186,35 +186,40 @@ __global__ __launch_bounds__(kLT) void resample_lds_kernel(const float *__restri
 
 
 // ---- matrix-core resampler -----------------------------------------------------------------------------------
-// workgroup (pb, grp): periods [16 pb, 16 pb + 16) x the output tiles of group grp.  LDS: 16 rows (periods) of
-// `pieces` 16-byte pieces = inputs [lo, lo + 4 pieces) of each period (pieces odd: the rows then start on all 16
-// bank groups).  Tile m (rows = outputs 16m..16m+15 of a period): K index w <-> input offset top[m] - w.
 constexpr int kRsTiles = 4;                    // output tiles per workgroup: one per wave
-constexpr int kRsPieces = 160;                 // pieces per staged row at most (16 rows x 160 x 16 B = 40 KB)
-constexpr int kRsLoads = (kRsPieces + 15) / 16;
+constexpr int kRsPieces = 160;                 // 16-byte pieces per staged row at most (16 rows x 161 x 16 B = 41 KB)
 
-// workgroup (pb, grp): periods [16 pb, 16 pb + 16) x output tiles [m0, m1) of group grp, wave w = tile m0 + w.
-// groups[4 grp ..] = m0, m1, lo, pieces: the 16 LDS rows hold inputs [lo, lo + 4 pieces) of each period (pieces odd: rows
-// then start on all 16 bank groups).  Tile m: K index w <-> input offset tile_top[m] - w inside the period.
-template <int KS4>
-__global__ __launch_bounds__(256) void resample_mfma_kernel(const float *__restrict__ x, long n_in, long g_min, long n_per,
+// workgroup (chain, grp): output tiles [m0, m1) of group grp (wave w = tile m0 + w, its taps resident in registers) x the period
+// blocks pb = 8 chain + xcd, + 8 n_chain, ...: 16 periods each.  groups[4 grp ..] = m0, m1, lo, pieces: the 16 LDS rows hold
+// inputs [lo, lo + 4 pieces) of each period, row stride pieces | 1 (odd: rows then start on all 16 bank groups), and one more
+// piece per row behind them takes what the staging threads read past a row's end.  Tile m: K index w <-> input offset
+// tile_top[m] - w inside the period.  The next block's inputs are fetched into registers before the current block's matrix
+// products and go to LDS behind them: one buffer, two barriers per block.
+// ELEM = false: x is 16-byte aligned and the caller vouches for finite, readable samples kRsFront in front of the history and
+// kRsBack behind the block (the pipeline's discriminator buffer has them): only taps that are zero ever meet those, so every
+// block is staged the same way, with one address register and instruction offsets.
+// ELEM = true: any x: element by element, outside [g_min, n_in) = a word that holds 0.0f (the tap image's first: K index 0 of
+// tile 0 lies past its band).
+template <int KS4, int NL, bool ELEM>
+__global__ __launch_bounds__(256, ELEM ? 2 : KS4 >= 14 ? 3 : 4) void resample_mfma_kernel(const float *__restrict__ x, long n_in, long g_min, long n_per,
                                                              const float *__restrict__ a_tab, const int *__restrict__ tile_top,
-                                                             const int *__restrict__ groups, int n_groups, int decim,
+                                                             const int *__restrict__ groups, int n_groups, int n_chain, int decim,
                                                              int upsamp, float *__restrict__ y, int16_t *__restrict__ pcm, int wrap)
 {
     extern __shared__ __attribute__((aligned(16))) float rows[];
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
-    // workgroup id -> (period block, group): workgroups go round the 8 XCDs by id, so id % 8 is kept the same for all groups
-    // of a period block and they are adjacent in dispatch order: the overlap of their windows is served by one L2
-    const int blk = blockIdx.x >> 3, xcd = blockIdx.x & 7;
-    const int g_idx = blk % n_groups;
-    const long pb = static_cast<long>(blk / n_groups) * 8 + xcd;
-    const long q0 = pb * 16;
-    if (q0 >= n_per) return;
+    // workgroup id -> (chain, group): workgroups go round the 8 XCDs by id, so id % 8 is kept the same for all groups of a
+    // period block and they are adjacent in dispatch order: the overlap of their windows is served by one L2
+    const int slot = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    const int g_idx = slot % n_groups;
+    const long npb = (n_per + 15) >> 4;
+    const long pb_step = 8L * n_chain;
+    long pb = static_cast<long>(slot / n_groups) * 8 + xcd;
+    if (pb >= npb) return;
     const int *grp = groups + 4 * g_idx;
     const int m0 = grp[0], m1 = grp[1], lo = grp[2], pieces = grp[3];
-    const int stride = 4 * pieces;
+    const int stride = 4 * (pieces | 1);
     const int m = m0 + wave;
     const bool have = m < m1;                                  // wave-uniform
     // this wave's taps first: their L2 round trip runs under the staging of the rows
@@ -225,68 +230,96 @@ __global__ __launch_bounds__(256) void resample_mfma_kernel(const float *__restr
         for (int jj = 0; jj < KS4; jj++) a[jj] = ap[jj];
     }
     const int top = tile_top[have ? m : m0];
-    {
-        // 16 threads per row (period), every thread up to kRsLoads pieces, all loads in flight before the first LDS write
-        const int row = t >> 4, c = t & 15;
-        long q = q0 + row;
-        q = q < n_per ? q : n_per - 1;                       // columns past the end repeat the last period (never stored)
-        const long gr = q * decim + lo;
-        float *dst = rows + row * stride;
-        f4 v[kRsLoads];
+    // staging: 16 threads per row (period), thread c the pieces c, c + 16, ... (NL of them)
+    const int row = t >> 4, c = t & 15;
+    f4 v[NL];
+    auto fetch = [&](long b) {
+        const long q0 = b * 16;
+        if constexpr (!ELEM) {
+            // rows past the last period repeat it (never stored)
+            const int last_row = static_cast<int>(min(15L, n_per - 1 - q0));
+            const unsigned voff = 4u * (static_cast<unsigned>(min(row, last_row)) * decim + 4 * c);   // bytes from the block's first piece
+            const char *base = reinterpret_cast<const char *>(x + (q0 * decim + lo));                 // uniform
 #pragma unroll
-        for (int u = 0; u < kRsLoads; u++) v[u] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
-        // 16-byte loads where the rows are 16-byte aligned (x is, unless the caller's all-pass delay shifted it by an odd count)
-        if (q0 > 0 && q0 + 16 < n_per && reinterpret_cast<uintptr_t>(x) % 16 == 0) {   // and no row reaches in front of the history or past the block
-#pragma unroll
-            for (int u = 0; u < kRsLoads; u++) {
-                const int pc = c + 16 * u;
-                if (pc < pieces) v[u] = *reinterpret_cast<const f4 *>(x + gr + 4 * pc);
-            }
+            for (int u = 0; u < NL; u++) v[u] = *reinterpret_cast<const f4 *>(base + (voff + 256u * u));
         } else {
+            long q = q0 + row;
+            q = q < n_per ? q : n_per - 1;
+            const long gr = q * decim + lo;
 #pragma unroll
-            for (int u = 0; u < kRsLoads; u++) {
-                const int pc = c + 16 * u;
-                const long g = gr + 4 * pc;
-                if (pc < pieces) {
+            for (int u = 0; u < NL; u++) {
+                const int pc = 4 * min(c + 16 * u, pieces - 1);          // past the row's end: its last piece again
 #pragma unroll
-                    for (int e = 0; e < 4; e++) v[u][e] = (g + e >= g_min && g + e < n_in) ? x[g + e] : 0.0f;
+                for (int e = 0; e < 4; e++) {
+                    const long g = gr + pc + e;
+                    v[u][e] = *((g >= g_min && g < n_in) ? x + g : a_tab);
                 }
             }
         }
+    };
+    auto put = [&]() {
+        int cz = c;
+        asm volatile("" : "+v"(cz));                           // the LDS addresses are recomputed here, not kept across the loop
 #pragma unroll
-        for (int u = 0; u < kRsLoads; u++) asm volatile("" : "+v"(v[u]));   // every load issued before the first LDS write
-#pragma unroll
-        for (int u = 0; u < kRsLoads; u++) {
-            const int pc = c + 16 * u;
-            if (pc < pieces) *reinterpret_cast<f4 *>(dst + 4 * pc) = v[u];
+        for (int u = 0; u < NL; u++) {
+            const int pc = cz + 16 * u;
+            const int sp = pieces | 1;                         // row stride in pieces
+            const int at = ELEM ? row * sp + min(pc, pieces - 1) : pc < pieces ? row * sp + pc : 16 * sp + row;
+            reinterpret_cast<f4 *>(rows)[at] = v[u];
         }
-    }
+    };
+    fetch(pb);
+    put();
 #pragma unroll
     for (int jj = 0; jj < KS4; jj++) asm volatile("" : "+v"(a[jj]));   // the taps stay in registers (not re-loaded at their use)
     __syncthreads();
-    if (!have) return;
     const int n = lane & 15, kq = lane >> 4;
     // this lane's operands of K-steps 4jj..4jj+3: inputs top - 16jj - 4kq - {0,1,2,3} of period n
     const float *bp = rows + n * stride + (top - 3 - lo) - 4 * kq;
-    f4 acc = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+    const int r = 16 * m + 4 * kq;
+    const bool whole = 16 * m + 16 <= upsamp;                  // wave-uniform: every row of the tile is an output
+    const float fu = static_cast<float>(upsamp);
+    for (;;) {
+        const long nxt = pb + pb_step;
+        const bool more = nxt < npb;                           // uniform over the workgroup
+        if (more) fetch(nxt);
+        if (have) {
+            f4 acc = (f4){0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int jj = 0; jj < KS4; jj++) {
-        const f4 xv = *reinterpret_cast<const f4 *>(bp - 16 * jj);
+            for (int jj = 0; jj < KS4; jj++) {
+                const f4 xv = *reinterpret_cast<const f4 *>(bp - 16 * jj);
 #pragma unroll
-        for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj][e], xv[3 - e], acc, 0, 0, 0);
-    }
-    const long q = q0 + n;
-    if (q < n_per) {
-        const int r = 16 * m + 4 * kq;
-        const long o = q * upsamp + r;
-#pragma unroll
-        for (int e = 0; e < 4; e++)
-            if (r + e < upsamp) {
-                const float gq = acc[e] * static_cast<float>(upsamp);   // y += y*U (src/filter.cpp:221), separately rounded
-                const float out = acc[e] + gq;
-                if (y) y[o + e] = out;
-                if (pcm) pcm[o + e] = pcm_pack(out, wrap);              // src/threadMonoOnly.cpp:185-191
+                for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj][e], xv[3 - e], acc, 0, 0, 0);
             }
+            const long q = pb * 16 + n;
+            f4 out;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float gq = acc[e] * fu;                  // y += y*U (src/filter.cpp:221), separately rounded
+                out[e] = acc[e] + gq;
+            }
+            if (q < n_per) {
+                const long o = q * upsamp + r;
+                if (whole && !y) {                             // the pipeline's case: s16 only (src/threadMonoOnly.cpp:185-191)
+                    struct __attribute__((packed)) S4 { int16_t s[4]; } pk;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) pk.s[e] = pcm_pack_flat(out[e], wrap);
+                    __builtin_memcpy(pcm + o, &pk, sizeof pk);   // one 8-byte store, 2-byte aligned
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (r + e < upsamp) {
+                            if (y) y[o + e] = out[e];
+                            if (pcm) pcm[o + e] = pcm_pack(out[e], wrap);
+                        }
+                }
+            }
+        }
+        if (!more) break;
+        __syncthreads();                                       // every wave has read this block's rows
+        put();
+        __syncthreads();
+        pb = nxt;
     }
 }
 
@@ -308,16 +341,15 @@ static int resample_mfma_plan(ResamplePlan &pl, const float *h)
         top[m] = (bmax + 1 + 3) / 4 * 4 - 1;
         K = std::max(K, top[m] - b0[m] + J);
     }
-    const int KS4 = (K + 15) / 16;
-    if (KS4 < 8 || KS4 > 16) return FMRX_OK;
+    const int KS4 = std::max(8, (K + 31) / 32 * 2);             // K-steps in sixteens: an even count from 8 to 16 (kernel instances)
+    if (KS4 > 16) return FMRX_OK;
     // tile groups of kRsTiles consecutive tiles (one per wave): a period's staged window = what the group's tiles read
     std::vector<int> grp;
     int max_pieces = 0;
     for (int m = 0; m < ntiles; m += kRsTiles) {
         const int m1 = std::min(m + kRsTiles, ntiles);
         const int lo = top[m] - 16 * KS4 + 1;                      // oldest input tile m reads; top % 4 == 3 -> a multiple of 4
-        int pieces = (top[m1 - 1] - lo + 1) / 4;
-        if (pieces % 2 == 0) pieces++;
+        const int pieces = (top[m1 - 1] - lo + 1) / 4;
         if (pieces > kRsPieces) return FMRX_OK;
         max_pieces = std::max(max_pieces, pieces);
         grp.insert(grp.end(), {m, m1, lo, pieces});
@@ -346,31 +378,77 @@ static int resample_mfma_plan(ResamplePlan &pl, const float *h)
     pl.mfma_ks4 = KS4;
     pl.mfma_ngroups = static_cast<int>(grp.size() / 4);
     pl.mfma_pieces = max_pieces;
+    // what piece staging reads: from the first period's lowest window start to the last period's highest one + 16 NL pieces
+    {
+        const int nl = std::max(4, (max_pieces + 15) / 16);
+        int lo_min = 0, lo_max = 0;
+        for (size_t g = 0; g < grp.size(); g += 4) {
+            lo_min = std::min(lo_min, grp[g + 2]);
+            lo_max = std::max(lo_max, grp[g + 2]);
+        }
+        pl.mfma_reach_ok = -lo_min <= kResampleFront && lo_max + 64 * nl - D <= kResampleBack;
+    }
     pl.mfma = true;
     return FMRX_OK;
 }
 
-template <int KS4>
+template <int KS4, int NL, bool ELEM>
 static int resample_mfma_launch_ks(const ResamplePlan &pl, const float *x, size_t n_in, float *d_y, int16_t *d_pcm, int wrap,
-                                   hipStream_t stream)
+                                   hipStream_t stream, int chains)
 {
     const long n_per = static_cast<long>(n_in / pl.decim);
-    const unsigned n_pb8 = static_cast<unsigned>((n_per + 127) / 128);   // period blocks, in eights
-    const size_t lds = static_cast<size_t>(16) * pl.mfma_pieces * 16;
-    hipLaunchKernelGGL(resample_mfma_kernel<KS4>, dim3(n_pb8 * 8 * pl.mfma_ngroups), dim3(256), lds, stream, x,
-                       static_cast<long>(n_in), -static_cast<long>(pl.J - 1), n_per, pl.mfma_img.p, pl.mfma_top.p,
-                       pl.mfma_groups.p, pl.mfma_ngroups, pl.decim, pl.upsamp, d_y, d_pcm, wrap);
+    const long npb8 = (n_per + 127) / 128;                               // period blocks per XCD
+    const size_t lds = (static_cast<size_t>(16) * (pl.mfma_pieces | 1) + 16) * 16;
+    int &wgs = pl.mfma_wgs_per_cu[ELEM ? 1 : 0];
+    if (wgs == 0) {
+        FMRX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs, resample_mfma_kernel<KS4, NL, ELEM>, 256, lds));
+        if (wgs < 1) wgs = 1;
+    }
+    // chains per XCD: as many workgroups as are resident at once (32 CUs per XCD), every chain the same number of blocks (+-1)
+    long cmax = std::max<long>(1, 32L * wgs / pl.mfma_ngroups);
+    if (chains > 0) cmax = chains;                                      // option resample_chains: A/B only
+    const long iters = (npb8 + cmax - 1) / cmax;
+    const long n_chain = (npb8 + iters - 1) / iters;
+    hipLaunchKernelGGL((resample_mfma_kernel<KS4, NL, ELEM>), dim3(static_cast<unsigned>(n_chain * 8 * pl.mfma_ngroups)), dim3(256),
+                       lds, stream, x, static_cast<long>(n_in), -static_cast<long>(pl.J - 1), n_per, pl.mfma_img.p,
+                       pl.mfma_top.p, pl.mfma_groups.p, pl.mfma_ngroups, static_cast<int>(n_chain), pl.decim, pl.upsamp, d_y,
+                       d_pcm, wrap);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FMRX_EHIP, "launch resample_mfma_kernel: %s", hipGetErrorString(e));
     return FMRX_OK;
 }
 
-static int resample_mfma_launch(const ResamplePlan &pl, const float *x, size_t n_in, float *d_y, int16_t *d_pcm, int wrap,
-                                hipStream_t stream)
+// loads per staging thread: an instance per count from 4 to 10 (piece staging), per even count (element staging)
+template <int KS4>
+static int resample_mfma_launch_nl(const ResamplePlan &pl, const float *x, size_t n_in, float *d_y, int16_t *d_pcm, int wrap,
+                                   hipStream_t stream, bool pieces16, int chains)
 {
+    const int nl = std::max(4, (pl.mfma_pieces + 15) / 16);
+    if (!pieces16) {
+        switch ((nl + 1) / 2 * 2) {
+#define X(N_) case N_: return resample_mfma_launch_ks<KS4, N_, true>(pl, x, n_in, d_y, d_pcm, wrap, stream, chains);
+            X(4) X(6) X(8) X(10)
+#undef X
+        }
+    } else {
+        switch (nl) {
+#define X(N_) case N_: return resample_mfma_launch_ks<KS4, N_, false>(pl, x, n_in, d_y, d_pcm, wrap, stream, chains);
+            X(4) X(5) X(6) X(7) X(8) X(9) X(10)
+#undef X
+        }
+    }
+    return fail(FMRX_EINVAL, "resample_mfma_launch: no kernel for %d pieces per row", pl.mfma_pieces);
+}
+
+static int resample_mfma_launch(const ResamplePlan &pl, const float *x, size_t n_in, float *d_y, int16_t *d_pcm, int wrap,
+                                hipStream_t stream, bool margins, int chains)
+{
+    // 16-byte pieces, every block staged alike: x aligned (it is, unless the caller's all-pass delay shifted it by a count that
+    // is not a multiple of 4) and samples to read on either side of the block
+    const bool pieces16 = margins && pl.mfma_reach_ok && reinterpret_cast<uintptr_t>(x) % 16 == 0;
     switch (pl.mfma_ks4) {
-#define X(K_) case K_: return resample_mfma_launch_ks<K_>(pl, x, n_in, d_y, d_pcm, wrap, stream);
-        X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+#define X(K_) case K_: return resample_mfma_launch_nl<K_>(pl, x, n_in, d_y, d_pcm, wrap, stream, pieces16, chains);
+        X(8) X(10) X(12) X(14) X(16)
 #undef X
     }
     return fail(FMRX_EINVAL, "resample_mfma_launch: no kernel for %d K-steps", 4 * pl.mfma_ks4);
@@ -418,16 +496,16 @@ int resample_plan_init(ResamplePlan &pl, const float *h, int taps, int decim, in
 
 // x points at the block start; x[-(J-1+delay) .. -1] must be readable history
 int resample_launch(const ResamplePlan &pl, const float *d_x, size_t n_in, int delay, float *d_y, const Options &o,
-                    hipStream_t stream, bool force_generic, bool exact, int16_t *d_pcm, int wrap)
+                    hipStream_t stream, bool force_generic, bool exact, int16_t *d_pcm, int wrap, bool margins)
 {
     const size_t n_out = (n_in * static_cast<size_t>(pl.upsamp)) / pl.decim;
     if (n_out == 0) return FMRX_OK;
     // the matrix-core kernel (float32-rounding-equal, not bit-exact: never for the primitive); it packs the PCM itself
     if (!force_generic && !exact && resample_mfma_available(pl, d_x, n_in, delay, o))
-        return resample_mfma_launch(pl, d_x - delay, n_in, d_y, d_pcm, wrap, stream);
+        return resample_mfma_launch(pl, d_x - delay, n_in, d_y, d_pcm, wrap, stream, margins, o.resample_chains);
     if (!d_y) return fail(FMRX_EINVAL, "resample_launch: this path needs the f32 output buffer");
     if (d_pcm) {   // every other kernel writes f32 only: pack behind it
-        FMRX_TRY(resample_launch(pl, d_x, n_in, delay, d_y, o, stream, force_generic, exact, nullptr, 0));
+        FMRX_TRY(resample_launch(pl, d_x, n_in, delay, d_y, o, stream, force_generic, exact, nullptr, 0, margins));
         return k_pcm16(d_y, n_out, d_pcm, wrap, stream);
     }
     if (!pl.fast || force_generic)

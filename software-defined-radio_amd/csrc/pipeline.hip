@@ -108,9 +108,22 @@ size_t n_audio_of(const fmrx_pipeline *pl, size_t n_bytes)
     return n_if / pl->p.audio_decim;
 }
 
+// resample_launch's margins hold for [d_x - delay, + n_in) iff it lies that far inside one of the discriminator buffers
+// ([Hd | n_if | margin], finite throughout); checked against the allocations, not assumed
+bool resample_margins(const fmrx_pipeline *pl, const float *d_x, size_t n_in, int delay)
+{
+    for (int i = 0; i < 2; i++) {
+        const float *b = pl->demod_buf[i].p, *e = b + pl->demod_buf[i].n;
+        if (b && d_x - delay - kResampleFront >= b && d_x - delay + n_in + kResampleBack <= e) return true;
+    }
+    return false;
+}
+
 int audio_stage(fmrx_pipeline *pl, const float *d_x, size_t n_in, int delay, float *d_y, hipStream_t s)
 {
-    if (pl->resample) return resample_launch(pl->rs, d_x, n_in, delay, d_y, pl->opt, s, pl->force_generic);
+    if (pl->resample)
+        return resample_launch(pl->rs, d_x, n_in, delay, d_y, pl->opt, s, pl->force_generic, false, nullptr, 0,
+                               resample_margins(pl, d_x, n_in, delay));
     return audio_fir_launch(pl->audio, d_x, nullptr, n_in, delay, d_y, nullptr, 0, s, pl->force_generic);
 }
 
@@ -194,6 +207,7 @@ int fmrx_pipeline_create(fmrx_pipeline **out, const fmrx_params *p, int channels
     pl->delay = channels == 2 ? (p->stereo_taps - 1) / 2 : 0;
     pl->Hd = pl->Ha + pl->delay;
     if (channels == 2 && pl->St - 1 + 3 > pl->Hd) pl->Hd = pl->St - 1 + 3;   // the band-pass pair kernel reads 16-byte chunks
+    if (pl->resample) pl->Hd += kResampleFront;   // the matrix-core resampler stages whole 16-byte pieces around its windows
     pl->Hd = (pl->Hd + 3) / 4 * 4 + 4;   // the specialised audio kernel loads aligned 16-byte chunks
     pl->Hm = (pl->Ha + 3) / 4 * 4 + 4;
 
@@ -223,7 +237,10 @@ int fmrx_pipeline_create(fmrx_pipeline **out, const fmrx_params *p, int channels
             FMRX_TRY(pl->prev_iq[i].alloc(2));
         }
         FMRX_TRY(pl->ifb.alloc(2 * n_if + 16));
-        for (int i = 0; i < 2; i++) FMRX_TRY(pl->demod_buf[i].alloc(pl->Hd + n_if + 16));
+        for (int i = 0; i < 2; i++) {   // [Hd | n_if | margin]: all of it finite from the start (resample_launch's margins)
+            FMRX_TRY(pl->demod_buf[i].alloc(pl->Hd + n_if + 16 + kResampleBack));
+            FMRX_HIP(hipMemset(pl->demod_buf[i].p, 0, (pl->Hd + n_if + 16 + kResampleBack) * sizeof(float)));
+        }
         FMRX_TRY(pl->tmp_hist.alloc(pl->Hd + pl->Hm + 16));
         FMRX_TRY(pl->mono.alloc(n_au));
         if (channels == 2) {
@@ -457,7 +474,8 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
             // the matrix-core kernel writes the caller's buffers itself; PCM-only callers get the reference's output
             // format and nothing else (as the fused mono kernel of modes 0/1)
             float *dst = d_audio_f32 ? d_audio_f32 : (d_pcm16 ? nullptr : pl->mono.p);
-            FMRX_TRY(resample_launch(pl->rs, demod, n_if, 0, dst, pl->opt, s, false, false, d_pcm16, pcm_policy));
+            FMRX_TRY(resample_launch(pl->rs, demod, n_if, 0, dst, pl->opt, s, false, false, d_pcm16, pcm_policy,
+                                     resample_margins(pl, demod, n_if, 0)));
             pl->last_mono = dst;
             if (prof) {
                 FMRX_HIP(hipEventRecord(ev[2], s));

@@ -467,13 +467,16 @@ def _run_blocks(pl, iq, bb, nblk):
     return outs
 
 
-@pytest.mark.parametrize("mode,periods", [(2, 64 + 13), (2, 400), (3, 64), (3, 171)])
-def test_resampler_matrix_core_kernel(fmrx, oracle, mode, periods):
+@pytest.mark.parametrize("mode,periods,chains", [(2, 64 + 13, 0), (2, 400, 0), (3, 64, 0), (3, 171, 0), (2, 1000 + 7, 1), (3, 419, 2)])
+def test_resampler_matrix_core_kernel(fmrx, oracle, mode, periods, chains):
     """Pipeline path of modes 2 / 3 from 64 periods (64 x 800 / 3200 IF samples) per call: the polyphase resampler as f32
     matrix-core tiles (16 outputs x 16 periods), which also packs the PCM.  Its sums are fma chains over the window instead
     of the reference's separately rounded products and sums: equal to float32 rounding, not bit for bit -- compared here
     with the bit-exact LDS-table kernel on the SAME discriminator output (option resample_exact), two consecutive calls
-    (carried history; period counts that are not multiples of the 16 a tile holds), then with the oracle end to end."""
+    (carried history; period counts that are not multiples of the 16 a tile holds), then with the oracle end to end.
+    chains > 0 (option resample_chains): that few workgroups per XCD and tile group, so that each walks several period blocks
+    (what happens by itself from a few thousand periods per call): the loop that stages the next block under the current
+    block's products, and the store held back by one round."""
     import torch
     p = fmrx.modeParams(mode)
     n_if = periods * p.audio_decim
@@ -483,6 +486,8 @@ def test_resampler_matrix_core_kernel(fmrx, oracle, mode, periods):
     a, b, po = fmrx.Pipeline(mode, 1, max_block_bytes=nb), fmrx.Pipeline(mode, 1, max_block_bytes=nb), oracle.pipeline(mode, 1)
     b.set_option("resample_exact", 1)
     c = fmrx.Pipeline(mode, 1, max_block_bytes=nb)          # PCM only, device buffers
+    a.set_option("resample_chains", chains)
+    c.set_option("resample_chains", chains)
     d_iq = torch.from_numpy(iq).cuda()
     d_pcm = torch.empty(a.n_audio(nb), dtype=torch.int16, device="cuda")
     for k in range(2):
@@ -778,6 +783,8 @@ def test_stereo_error_envelope_seconds_into_a_stream(fmrx, oracle, mode, seconds
     nblk = int(seconds * p.rf_Fs / (p.block_bytes // 2)) // 60 * 60
     iq = oracle.synth_fm_u8(p.block_bytes // 2 * nblk, rf_Fs=p.rf_Fs, seed=0x3D74)
     po, pl = oracle.pipeline(mode, 2), fmrx.Pipeline(mode, 2, max_block_bytes=60 * p.block_bytes)
+    if mode == 2:   # the matrix-core resampler's workgroups walk several period blocks each (element staging: the all-pass delay
+        pl.set_option("resample_chains", 1)   # of 50 samples leaves its input 8-byte aligned), as in much larger calls
     ref = [po.process(iq[o:o + p.block_bytes]) for o in range(0, len(iq), p.block_bytes)]
     out = [pl.process(iq[o:o + 60 * p.block_bytes]) for o in range(0, len(iq), 60 * p.block_bytes)]
     if_Fs = p.rf_Fs / p.rf_decim
