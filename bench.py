@@ -293,7 +293,7 @@ def side_legs(torch, fmrx, synth, args, pl, step, d_iq, n_bytes, stream) -> dict
     fmrx.set_option("fe_variant", "mfma")
     del d_if, plan
     # (4) the other modes / stereo, streaming (state carried), device-resident
-    def mode_leg(name, mode, channels, blocks, what, bytes_per_sample, bytes_unit, base_blocks=1):
+    def mode_leg(name, mode, channels, blocks, what, bytes_per_sample, bytes_unit, base_blocks=1, options=None):
         # base_blocks blocks are synthesised and repeated; stereo needs a seamless stream (a splice is a pilot phase
         # jump: the PLL would un-lock and be repaired): 3 x 1,024,000 samples = 1280 periods of the 1 ms multiplex
         p = fmrx.modeParams(mode)
@@ -301,6 +301,8 @@ def side_legs(torch, fmrx, synth, args, pl, step, d_iq, n_bytes, stream) -> dict
         iq = synth.synth_fm_u8(base_blocks * bytes_unit // 2, float(p.rf_Fs), seed=0x3D74 + 10 + mode)
         d_in = torch.from_numpy(iq).cuda().repeat(blocks // base_blocks)
         q = fmrx.Pipeline(mode, channels, max_block_bytes=nb, device=torch.cuda.current_device())
+        for key, val in (options or {}).items():
+            q.set_option(key, val)
         na = q.n_audio(nb)
         d_pcm = torch.empty(channels * na, dtype=torch.int16, device="cuda")
         fn = lambda: q.process_dev(d_in.data_ptr(), nb, None, d_pcm.data_ptr(), wrap=True, stream=stream)
@@ -327,6 +329,13 @@ def side_legs(torch, fmrx, synth, args, pl, step, d_iq, n_bytes, stream) -> dict
              2.0 + 4.0 / 50.0, 2048000, base_blocks=3)
     mode_leg("mode0_stereo_24_blocks", 0, 2, 24, "mode 0 stereo, 24 x 1,024,000-sample blocks per step (the PLL's 128-step lanes are a fixed cost per "
              "call up to ~40 blocks), stream continued", 2.0 + 4.0 / 50.0, 2048000, base_blocks=3)
+    # the same with option overlap_calls = 1: the caller vouches that a call's input is complete when the call is made (it is:
+    # resident in HBM), and the next call's front end + band-pass pair + PLL chunk records run on an internal stream under
+    # this call's PLL lanes and output stage; same kernels, same results (tests: bit-identical PCM and state)
+    mode_leg("mode0_stereo_overlapped", 0, 2, 12, "mode 0 stereo, 12 x 1,024,000-sample blocks per step, option overlap_calls = 1 (consecutive calls "
+             "software-pipelined over two streams), stream continued", 2.0 + 4.0 / 50.0, 2048000, base_blocks=3, options={"overlap_calls": 1})
+    mode_leg("mode0_stereo_18_blocks_overlapped", 0, 2, 18, "mode 0 stereo, 18 x 1,024,000-sample blocks per step, option overlap_calls = 1, stream continued",
+             2.0 + 4.0 / 50.0, 2048000, base_blocks=3, options={"overlap_calls": 1})
     # (5) a live channel's regime: reference-size blocks (51,200 samples), one call per block, device-resident
     q = fmrx.Pipeline(0, 1, device=torch.cuda.current_device())
     d_pcm = torch.empty(1024, dtype=torch.int16, device="cuda")

@@ -59,6 +59,7 @@ bool option_ref(Options &o, const char *name, long **as_long, int **as_int)
     else if (n == "pll_align") *as_int = &o.pll_align;
     else if (n == "pll_mode") *as_int = &o.pll_mode;
     else if (n == "resample_chains") *as_int = &o.resample_chains;
+    else if (n == "overlap_calls") *as_int = &o.overlap_calls;
     else if (n == "fused_tune") *as_int = &o.fused_tune;
     else if (n == "fe_mfma_tune") *as_int = &o.fe_mfma_tune;
     else return false;
@@ -75,6 +76,7 @@ Options &default_options()
         if (std::getenv("FMRX_RESAMPLE_L2")) d.resample_l2 = 1;
         if (const char *e = std::getenv("FMRX_RESAMPLE_EXACT")) d.resample_exact = std::atoi(e);
         if (const char *e = std::getenv("FMRX_RESAMPLE_CHAINS")) d.resample_chains = std::atoi(e);
+        if (const char *e = std::getenv("FMRX_OVERLAP_CALLS")) d.overlap_calls = std::atoi(e);
         if (const char *e = std::getenv("FMRX_FE_WGS_PER_CU")) d.fe_wgs_per_cu = std::atoi(e);
         if (const char *e = std::getenv("FMRX_PLL_WARMUP")) d.pll_warmup = std::atoi(e);
         if (const char *e = std::getenv("FMRX_PLL_SEGMENT")) d.pll_segment = std::atoi(e);

@@ -47,6 +47,9 @@ struct Options {
     int resample_l2 = 0;           // "resample_l2" / FMRX_RESAMPLE_L2: 1 = L2-table resampler kernel even for large calls
     int resample_exact = 0;        // "resample_exact" / FMRX_RESAMPLE_EXACT: 1 = the pipeline's resampler keeps the reference's rounding sequence
                                    //   (the bit-exact LDS-table kernel instead of the matrix-core one)
+    int overlap_calls = 0;         // "overlap_calls" / FMRX_OVERLAP_CALLS: 1 = the caller vouches that a process_dev call's input is complete when the call
+                                   //   is made (data resident in HBM): the stereo pipeline then runs front end, PLL and output stage of consecutive
+                                   //   calls on three internal streams, one call apart each; the caller's stream still waits for each call's output
     int resample_chains = 0;       // "resample_chains" / FMRX_RESAMPLE_CHAINS: workgroups per XCD and tile group of the matrix-core resampler
                                    //   (0 = as many as are resident at once); A/B knob
     int fe_wgs_per_cu = 0;         // "fe_wgs_per_cu" / FMRX_FE_WGS_PER_CU: cap on resident workgroups per CU of the front-end kernels (0 = auto)
@@ -254,7 +257,12 @@ constexpr float kPllTolPhase = 1e-2f, kPllTolInteg = 1e-4f;
 size_t pll_parallel_scratch_floats(size_t n);
 int k_fm_pll_parallel(const float *d_in, size_t n, float *d_out, float *d_state, float freq, float Fs, float ncoScale,
                       float phaseAdjust, float normBandwidth, float *d_scratch, const Options &o, hipStream_t s,
-                      double off_hint = -1.0);   // off_hint: IF samples of the stream in front of this call (the state's trigOffset), < 0 = unknown
+                      double off_hint = -1.0,    // off_hint: IF samples of the stream in front of this call (the state's trigOffset), < 0 = unknown
+                      int phases = 3, float *d_lti = nullptr);
+// phases: 1 = only what depends on the input alone (the linear system's chunk records), 2 = the lanes and the repair, 3 = both;
+// d_lti: where the chunk records live (pll_parallel_lti_floats(n) floats, 8-byte aligned) if not inside d_scratch -- a caller
+// that runs phase 1 of its next call on another stream while phase 2 of this one reads them keeps two
+size_t pll_parallel_lti_floats(size_t n);
 int k_mix(const float *d_bpf, const float *d_pll, size_t n, float *d_mix, hipStream_t s);
 int k_combine(const float *d_st, const float *d_mono, size_t n, float *d_l, float *d_r, hipStream_t s);
 int k_upsample(const float *d_x, size_t n, float *d_xu, int up, hipStream_t s);

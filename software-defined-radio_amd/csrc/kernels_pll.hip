@@ -677,8 +677,15 @@ size_t pll_parallel_scratch_floats(size_t n)
     return 8 + nseg * 16 + 2 * (nseg / 64 + 2) + 2 + (nchunk + 2) * 8 + 2 * (nchunk / 64 + 2);   // + chunk records (4 doubles), workgroup totals
 }
 
+size_t pll_parallel_lti_floats(size_t n)
+{
+    const size_t nchunk = n / kLtiChunk + 2;
+    return (nchunk + 2) * 8 + 2 * (nchunk / 64 + 2) + 2;
+}
+
 int k_fm_pll_parallel(const float *d_in, size_t n, float *d_out, float *d_state, float freq, float Fs, float ncoScale,
-                      float phaseAdjust, float normBandwidth, float *d_scratch, const Options &o, hipStream_t s, double off_hint)
+                      float phaseAdjust, float normBandwidth, float *d_scratch, const Options &o, hipStream_t s, double off_hint,
+                      int phases, float *d_lti)
 {
     int L = kPllSegment, W = kPllWarmup;
     if (o.pll_warmup >= 0 && o.pll_warmup <= 65536) W = o.pll_warmup / 4 * 4;                    // tuning: warm-up samples per lane
@@ -697,8 +704,11 @@ int k_fm_pll_parallel(const float *d_in, size_t n, float *d_out, float *d_state,
     }
     if (reinterpret_cast<uintptr_t>(d_in) % 16)
         return fail(FMRX_EINVAL, "fm_pll_parallel: input must be 16-byte aligned (the lanes fetch 16-byte groups)");
-    if (n < static_cast<size_t>(4 * L))   // nothing to gain
+    if (d_lti && reinterpret_cast<uintptr_t>(d_lti) % 8) return fail(FMRX_EINVAL, "fm_pll_parallel: chunk records must be 8-byte aligned");
+    if (n < static_cast<size_t>(4 * L)) {   // nothing to gain
+        if (!(phases & 2)) return FMRX_OK;
         return k_fm_pll(d_in, n, d_out, d_state, freq, Fs, ncoScale, phaseAdjust, normBandwidth, 1, s);
+    }
     PllCoef c = make_coef(freq, Fs, ncoScale, phaseAdjust, normBandwidth);
     // the loop's state repeats every P samples on an on-frequency pilot: Fs / gcd(Fs, freq), when both are whole Hz
     int P = 0;
@@ -723,14 +733,17 @@ int k_fm_pll_parallel(const float *d_in, size_t n, float *d_out, float *d_state,
         const size_t mask_floats = 2 * (static_cast<size_t>(nseg) / 64 + 2);
         size_t off = 8 + (static_cast<size_t>(nseg) + 1) * 16 + mask_floats;
         off += off & 1;                                            // doubles
-        double *rec = reinterpret_cast<double *>(d_scratch + off);
+        double *rec = reinterpret_cast<double *>(d_lti ? d_lti : d_scratch + off);
         double *wgtot = rec + 4 * (nchunk + 1);
-        hipLaunchKernelGGL(pll_lti_chunks_kernel, dim3(static_cast<unsigned>((nchunk + 63) / 64)), dim3(64), 0, s, d_in,
-                           static_cast<long>(n), c, nchunk, rec, wgtot);
-        FMRX_LAUNCH_CHECK("pll_lti_chunks");
+        if (phases & 1) {
+            hipLaunchKernelGGL(pll_lti_chunks_kernel, dim3(static_cast<unsigned>((nchunk + 63) / 64)), dim3(64), 0, s, d_in,
+                               static_cast<long>(n), c, nchunk, rec, wgtot);
+            FMRX_LAUNCH_CHECK("pll_lti_chunks");
+        }
         lti_rec = rec;
         lti_wgtot = wgtot;
     }
+    if (!(phases & 2)) return FMRX_OK;
     hipLaunchKernelGGL(pll_segments_kernel, dim3(grid), dim3(kSegThreads), 0, s, d_in, static_cast<long>(n), d_out, d_state, c, L, W, P,
                        nseg, seg, d_scratch, lti_rec, lti_wgtot, badmask, kPllTolPhase, kPllTolInteg);
     FMRX_LAUNCH_CHECK("pll_segments");

@@ -67,6 +67,15 @@ struct fmrx_pipeline {
     size_t demod_n_last = 0;     // its length; its history front is valid iff demod_front[demod_last]
     bool demod_front[2] = {true, true};
     DevBuf<float> carrier, bpf, pll, pll_state, pll_scratch, mixer, st_final, left, right;
+    // option overlap_calls (stereo, modes 0/1, parallel PLL): the three stages of a call run on internal streams, a call apart
+    // each -- front (front end, band-pass pair, the PLL's chunk records), PLL (lanes + repair), output stage -- on the buffer
+    // set of the call's parity (set 0 = the buffers above); the caller's stream waits for the output stage's event
+    DevBuf<float> carrier1, bpf1, pll1, lti_rec[2];
+    hipStream_t ov_stream[3] = {};   // front, PLL, output
+    hipEvent_t ov_done[3][2] = {};   // [stage][parity]: the stage of the last call of that parity has finished
+    hipEvent_t ov_entry = nullptr;   // the caller's stream at the call: what it did with the previous output is over
+    int ov_active = 0;               // the regime (option value) of the last call
+    int last_set = 0;                // buffer set the last call used (read_tap)
     // state_stereofilt: the mixer output's last Hm samples (index Hm+g holds sample g < 0), written by one call
     // and read by the next: two buffers used alternately, mix_cur = the one the next call reads
     DevBuf<float> mix_tail[2];
@@ -284,6 +293,15 @@ int fmrx_pipeline_destroy(fmrx_pipeline *pl)
     for (auto &q : pl->ev)
         for (auto &e : q)
             if (e) (void)hipEventDestroy(e);
+    for (auto &st : pl->ov_stream)
+        if (st) {
+            (void)hipStreamSynchronize(st);
+            (void)hipStreamDestroy(st);
+        }
+    for (auto &q : pl->ov_done)
+        for (auto &e : q)
+            if (e) (void)hipEventDestroy(e);
+    if (pl->ov_entry) (void)hipEventDestroy(pl->ov_entry);
     delete pl;
     return FMRX_OK;
 }
@@ -342,6 +360,22 @@ int fmrx_pipeline_set_force_generic(fmrx_pipeline *pl, int on)
     return FMRX_OK;
 }
 
+// internal streams, events and the second buffer set of option overlap_calls, on first use
+static int overlap_setup(fmrx_pipeline *pl)
+{
+    if (pl->ov_stream[0]) return FMRX_OK;
+    const size_t n_if = (pl->max_bytes / 2) / pl->p.rf_decim;
+    FMRX_TRY(pl->carrier1.alloc(pl->carrier.n));
+    FMRX_TRY(pl->bpf1.alloc(pl->bpf.n));
+    FMRX_TRY(pl->pll1.alloc(pl->pll.n));
+    for (auto &b : pl->lti_rec) FMRX_TRY(b.alloc(pll_parallel_lti_floats(n_if) + 2));
+    for (auto &q : pl->ov_done)
+        for (auto &e : q) FMRX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    FMRX_HIP(hipEventCreateWithFlags(&pl->ov_entry, hipEventDisableTiming));
+    for (int i = 2; i >= 0; i--) FMRX_HIP(hipStreamCreateWithFlags(&pl->ov_stream[i], hipStreamNonBlocking));
+    return FMRX_OK;
+}
+
 int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_bytes, float *d_audio_f32,
                               int16_t *d_pcm16, int pcm_policy, void *stream)
 {
@@ -381,6 +415,33 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
     bool hist_done = false;
     pl->demod_valid = true;
     const bool mfma = pl->opt.fe_variant == 0;
+    // option overlap_calls: front / PLL / output stage of the stereo chain on three internal streams (see the struct)
+    const bool ovl = pl->opt.overlap_calls != 0 && pl->channels == 2 && !pl->resample && !pl->force_generic && !pl->keep_if &&
+                     !pl->profiling && pl->opt.pll_mode == 0 && mfma && n_if >= static_cast<size_t>(pl->Hd) &&
+                     fe_mfma_available(pl->fe, d_iq, n, hist) && stereo_out_available(p.audio_taps, p.audio_decim);
+    const int regime = ovl ? pl->opt.overlap_calls : 0;
+    if (regime != pl->ov_active) {   // change of regime between calls: everything in flight first
+        FMRX_HIP(hipDeviceSynchronize());
+        pl->ov_active = regime;
+    }
+    if (ovl) FMRX_TRY(overlap_setup(pl));
+    // overlap_calls 1: the front on an internal stream, PLL and output stage on the caller's (fewest event operations: at these
+    // step sizes the host's enqueue rate is the next limit); 2: all three on internal streams
+    const bool ovl3 = ovl && pl->opt.overlap_calls >= 2;
+    hipStream_t sf = ovl ? pl->ov_stream[0] : s, sp = ovl3 ? pl->ov_stream[1] : s, so = ovl3 ? pl->ov_stream[2] : s;
+    const int bs = ovl ? cur : 0;   // buffer set of the stereo intermediates
+    pl->last_set = bs;
+    float *carrier_b = bs ? pl->carrier1.p : pl->carrier.p, *bpf_b = bs ? pl->bpf1.p : pl->bpf.p, *pll_b = bs ? pl->pll1.p : pl->pll.p;
+    if (ovl) {
+        // the front writes this parity's buffers: the last call of the same parity must be through with them; the output
+        // stage writes the caller's buffers: whatever the caller's stream still does with them comes first (the input is the
+        // one thing the option vouches for)
+        FMRX_HIP(hipStreamWaitEvent(sf, pl->ov_done[2][cur], 0));
+        if (so != s) {
+            FMRX_HIP(hipEventRecord(pl->ov_entry, s));
+            FMRX_HIP(hipStreamWaitEvent(so, pl->ov_entry, 0));
+        }
+    }
     if (pl->channels == 1 && !pl->resample && !pl->force_generic && !pl->keep_if && mfma &&
         n_if >= static_cast<size_t>(pl->Hd) && static_cast<long>(n_au) >= pl->opt.fused_min_audio &&
         mono_fused_available(pl->fe, pl->audio, d_iq, n, hist)) {
@@ -419,7 +480,7 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
         const bool want_front = !(pl->channels == 1 && !pl->resample) && n_if >= static_cast<size_t>(pl->Hd);
         FMRX_TRY(fe_mfma_launch(pl->fe, d_iq, n, hist, pl->prev_override ? prev : nullptr, demod,
                                 pl->keep_if ? pl->ifb.p : nullptr, prev_next,
-                                hist_done ? hist_next : nullptr, pl->opt, s, want_front ? hist_end - pl->Hd : nullptr,
+                                hist_done ? hist_next : nullptr, pl->opt, sf, want_front ? hist_end - pl->Hd : nullptr,
                                 want_front ? dbuf : nullptr, pl->Hd));
         if (want_front) pl->demod_front[cur] = true;
         pl->if_valid = pl->keep_if;
@@ -440,7 +501,7 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
     pl->fe_cur ^= 1;
     if (prof) FMRX_HIP(hipEventRecord(ev[1], s));
     if (!hist_done)
-        hipLaunchKernelGGL(hist_update_kernel, dim3((hb + 255) / 256), dim3(256), 0, s, hist, d_iq,
+        hipLaunchKernelGGL(hist_update_kernel, dim3((hb + 255) / 256), dim3(256), 0, sf, hist, d_iq,
                            static_cast<long>(n_bytes), hb, hist_next);
     // a block shorter than the history keeps its own front valid, so that "tail of the previous
     // buffer" stays a contiguous Hd samples for whoever comes next
@@ -494,11 +555,11 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
             FMRX_TRY(audio_stage(pl, demod, n_if, pl->delay, pl->mono.p, s));  // all-pass = index offset
         }
         if (prof) FMRX_HIP(hipEventRecord(ev[2], s));
-        FMRX_TRY(bpf_pair_launch(pl->bpf_plan, demod, n_if, pl->bpf.p, pl->carrier.p, s, pl->force_generic));
+        FMRX_TRY(bpf_pair_launch(pl->bpf_plan, demod, n_if, bpf_b, carrier_b, sf, pl->force_generic));
         if (pl->force_generic || pl->opt.pll_mode != 0) {
             // the serial recurrence: glibc's functions in the bit-exact mode (and pll_mode 2), fast math for pll_mode 1
             const int fast = !pl->force_generic && pl->opt.pll_mode == 1;
-            FMRX_TRY(k_fm_pll(pl->carrier.p, n_if, pl->pll.p, pl->pll_state.p, 19e3f, static_cast<float>(p.if_Fs), 2.0f,
+            FMRX_TRY(k_fm_pll(carrier_b, n_if, pll_b, pl->pll_state.p, 19e3f, static_cast<float>(p.if_Fs), 2.0f,
                               0.0f, 0.01f, fast, s));
         } else {
             // a stream's first block starts unlocked: walk its first samples serially so that the
@@ -507,25 +568,44 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
             if (!pl->pll_warm) {
                 const size_t head_len = pl->opt.pll_head >= 0 ? static_cast<size_t>(pl->opt.pll_head) : kPllHead;
                 head = n_if < head_len ? n_if : head_len;
-                FMRX_TRY(k_fm_pll(pl->carrier.p, head, pl->pll.p, pl->pll_state.p, 19e3f, static_cast<float>(p.if_Fs),
-                                  2.0f, 0.0f, 0.01f, 1, s));
             }
+            // what depends on the input alone (the linear system's chunk records) belongs to the front
+            float *lti = ovl ? pl->lti_rec[cur].p : nullptr;
+            if (ovl && n_if > head)
+                FMRX_TRY(k_fm_pll_parallel(carrier_b + head, n_if - head, pll_b + head, pl->pll_state.p, 19e3f,
+                                           static_cast<float>(p.if_Fs), 2.0f, 0.0f, 0.01f, pl->pll_scratch.p, pl->opt, sf,
+                                           pl->pll_off + static_cast<double>(head), 1, lti));
+            if (ovl) {
+                FMRX_HIP(hipEventRecord(pl->ov_done[0][cur], sf));
+                FMRX_HIP(hipStreamWaitEvent(sp, pl->ov_done[0][cur], 0));
+            }
+            if (head > 0)
+                FMRX_TRY(k_fm_pll(carrier_b, head, pll_b, pl->pll_state.p, 19e3f, static_cast<float>(p.if_Fs),
+                                  2.0f, 0.0f, 0.01f, 1, sp));
             if (n_if > head)
-                FMRX_TRY(k_fm_pll_parallel(pl->carrier.p + head, n_if - head, pl->pll.p + head, pl->pll_state.p, 19e3f,
-                                           static_cast<float>(p.if_Fs), 2.0f, 0.0f, 0.01f, pl->pll_scratch.p, pl->opt, s,
-                                           pl->pll_off + static_cast<double>(head)));
+                FMRX_TRY(k_fm_pll_parallel(carrier_b + head, n_if - head, pll_b + head, pl->pll_state.p, 19e3f,
+                                           static_cast<float>(p.if_Fs), 2.0f, 0.0f, 0.01f, pl->pll_scratch.p, pl->opt, sp,
+                                           pl->pll_off + static_cast<double>(head), ovl ? 2 : 3, lti));
             pl->pll_warm = true;
+            if (so != sp) {
+                FMRX_HIP(hipEventRecord(pl->ov_done[1][cur], sp));
+                FMRX_HIP(hipStreamWaitEvent(so, pl->ov_done[1][cur], 0));
+            }
         }
         pl->pll_off += static_cast<double>(n_if);
         const float *tail_in = pl->mix_tail[pl->mix_cur].p;
         float *tail_out = pl->mix_tail[pl->mix_cur ^ 1].p;
         if (fused_out) {
             // mixer, both audio FIRs, L/R combine and PCM in one kernel, straight into the caller's buffers
-            FMRX_TRY(stereo_out_launch(demod, pl->bpf.p, pl->pll.p, tail_in, tail_out, pl->Hm, n_if, pl->delay, pl->audio.h.p,
+            FMRX_TRY(stereo_out_launch(demod, bpf_b, pll_b, tail_in, tail_out, pl->Hm, n_if, pl->delay, pl->audio.h.p,
                                        p.audio_taps, p.audio_decim, pl->mono.p, pl->st_final.p,
                                        d_audio_f32 ? d_audio_f32 : (d_pcm16 ? nullptr : pl->left.p),
                                        d_audio_f32 ? d_audio_f32 + n_au : (d_pcm16 ? nullptr : pl->right.p), d_pcm16,
-                                       pcm_policy, pl->keep_if ? mixer : nullptr, s));
+                                       pcm_policy, pl->keep_if ? mixer : nullptr, so));
+            if (ovl) {   // the caller's stream sees the call's output in its own order, as always
+                FMRX_HIP(hipEventRecord(pl->ov_done[2][cur], so));
+                if (so != s) FMRX_HIP(hipStreamWaitEvent(s, pl->ov_done[2][cur], 0));
+            }
             pl->mixer_valid = pl->keep_if;
             pl->mix_cur ^= 1;
             if (prof) {
@@ -535,7 +615,7 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
             return FMRX_OK;
         }
         FMRX_HIP(hipMemcpyAsync(pl->mixer.p, tail_in, pl->Hm * sizeof(float), hipMemcpyDeviceToDevice, s));
-        FMRX_TRY(k_mix(pl->bpf.p, pl->pll.p, n_if, mixer, s));
+        FMRX_TRY(k_mix(bpf_b, pll_b, n_if, mixer, s));
         FMRX_TRY(audio_stage(pl, mixer, n_if, 0, pl->st_final.p, s));
         FMRX_TRY(k_combine(pl->st_final.p, pl->mono.p, n_au, pl->left.p, pl->right.p, s));
         // the mixer output's last Hm samples (of [history | block]) are the next block's state_stereofilt
@@ -602,9 +682,9 @@ int fmrx_pipeline_read_tap(fmrx_pipeline *pl, int which, float *out, size_t *n)
         src = pl->last_mono; cnt = n_au;
         if (!src && out && cnt) return fail(FMRX_EINVAL, "read_tap: the last call wrote s16 PCM only (no f32 audio buffer was passed)");
         break;
-    case FMRX_TAP_CARRIER: if (st) { src = pl->carrier.p; cnt = n_if; } break;
-    case FMRX_TAP_STEREO_BPF: if (st) { src = pl->bpf.p; cnt = n_if; } break;
-    case FMRX_TAP_PLL: if (st) { src = pl->pll.p; cnt = n_if + 1; } break;
+    case FMRX_TAP_CARRIER: if (st) { src = pl->last_set ? pl->carrier1.p : pl->carrier.p; cnt = n_if; } break;
+    case FMRX_TAP_STEREO_BPF: if (st) { src = pl->last_set ? pl->bpf1.p : pl->bpf.p; cnt = n_if; } break;
+    case FMRX_TAP_PLL: if (st) { src = pl->last_set ? pl->pll1.p : pl->pll.p; cnt = n_if + 1; } break;
     case FMRX_TAP_MIXER:
         if (st) { src = pl->mixer.p + pl->Hm; cnt = n_if; }
         if (st && out && cnt && !pl->mixer_valid)

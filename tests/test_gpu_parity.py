@@ -773,6 +773,52 @@ def test_stereo_parallel_pll_matches_serial(fmrx, oracle, pll_start):
     assert rep == 0 and dp <= 5e-3          # a clean locked signal: every segment merged
 
 
+@pytest.mark.parametrize("mode,lanes", [(0, 1), (1, 1), (0, 2)])
+def test_stereo_overlapped_calls(fmrx, oracle, mode, lanes):
+    """Option overlap_calls (1: the next call's front end under this call's PLL and output stage; 2: front end / PLL / output
+    stage of consecutive process_dev calls on three internal streams), two sets of intermediates.  Same kernels on the same data in the same order per stage: the PCM, the carried
+    state and the PLL diagnostics equal the plain form's bit for bit -- over 7 calls of 3 blocks of a seamless stream (the
+    first starts unlocked: serial head), once with an output buffer per call and once with ONE output buffer that the caller's
+    stream copies away after each call (the output stage must not overtake that copy).  The plain form's parity with the
+    reference is what every other stereo test establishes."""
+    import torch
+    p = fmrx.modeParams(mode)
+    calls, per_call = 7, 3
+    nb = per_call * p.block_bytes
+    iq = oracle.synth_fm_u8(calls * nb // 2, rf_Fs=p.rf_Fs, seed=0x3D74 + mode)
+    d_iq = torch.from_numpy(iq).cuda()
+    s = torch.cuda.current_stream().cuda_stream
+    res = {}
+    for ovl in (0, 1):
+        pl = fmrx.Pipeline(mode, 2, max_block_bytes=nb)
+        pl.set_option("overlap_calls", ovl * lanes)
+        na = pl.n_audio(nb)
+        outs = [torch.empty(2 * na, dtype=torch.int16, device="cuda") for _ in range(calls)]
+        for k in range(calls):
+            pl.process_dev(d_iq.data_ptr() + k * nb, nb, None, outs[k].data_ptr(), stream=s)
+        torch.cuda.synchronize()
+        st, diag, nco = pl.get_state(), pl.pll_diagnostics(), pl.read_tap("pll")
+        # one output buffer, copied away on the caller's stream behind each call
+        pl.reset()
+        one = torch.empty(2 * na, dtype=torch.int16, device="cuda")
+        kept = [torch.empty_like(one) for _ in range(calls)]
+        for k in range(calls):
+            pl.process_dev(d_iq.data_ptr() + k * nb, nb, None, one.data_ptr(), stream=s)
+            kept[k].copy_(one, non_blocking=True)
+        torch.cuda.synchronize()
+        res[ovl] = (outs, st, diag, nco, kept)
+        pl.close()
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    for a, b in zip(res[0][0], res[1][4]):
+        assert torch.equal(a, b)
+    for a, b in zip(res[0][0], res[0][4]):
+        assert torch.equal(a, b)
+    np.testing.assert_array_equal(res[0][1], res[1][1])          # carried state
+    assert res[0][2][0] == res[1][2][0]                          # repaired PLL segments
+    np.testing.assert_array_equal(res[0][3], res[1][3])          # the last call's NCO (read from the buffer set it used)
+
+
 @pytest.mark.parametrize("mode,seconds", [(0, 12.0), (1, 6.0), (2, 6.0), (3, 9.0)])
 def test_stereo_error_envelope_seconds_into_a_stream(fmrx, oracle, mode, seconds):
     """The envelope beyond the committed fixture, in every mode (IF rates 240 / 288 / 240 / 320 kHz): a synthetic stream of
