@@ -224,14 +224,17 @@ def spawn_ranks(n: int, argv: list[str]) -> int:
 # ------------------------------------------------------------------------------------------------
 # device-side measurement helpers
 # ------------------------------------------------------------------------------------------------
-def event_ms(torch, step, k: int, warm: int = 3) -> float:
+def event_ms(torch, step, k: int, warm: int = 3, drain: bool = True) -> float:
     """Average device time of one step: HIP events on the launch stream (torch's current stream, the one
     every step is submitted to) around k back-to-back steps.  Includes the dispatch gap between
-    consecutive kernels (1-2 us), subtracts nothing."""
+    consecutive kernels (1-2 us), subtracts nothing.  drain = False: the timed steps follow the warm-up steps
+    without a device-wide wait in between (the few-step stereo legs: a software pipeline over consecutive calls
+    would otherwise be timed with its fill)."""
     for _ in range(warm):
         step()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
+    if drain:
+        torch.cuda.synchronize()
     e0.record()
     for _ in range(k):
         step()
@@ -313,7 +316,7 @@ def side_legs(torch, fmrx, synth, args, pl, step, d_iq, n_bytes, stream) -> dict
             q.reset()
             n_if = nb // 2 // int(p.rf_decim)
             warm = 2 if 6 * n_if < 7_500_000 else 1
-            ms = event_ms(torch, fn, max(2, min(8, 7_500_000 // n_if - warm)), warm=warm)
+            ms = event_ms(torch, fn, max(2, min(8, 7_500_000 // n_if - warm)), warm=warm, drain=False)
         else:
             ms = event_ms(torch, fn, k, warm=5)
         nm, d = leg(name, what, nb // 2, ms, bytes_per_sample)

@@ -415,7 +415,7 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
     bool hist_done = false;
     pl->demod_valid = true;
     const bool mfma = pl->opt.fe_variant == 0;
-    // option overlap_calls: front / PLL / output stage of the stereo chain on three internal streams (see the struct)
+    // option overlap_calls: front | PLL | output stage of the stereo chain of consecutive calls on internal streams (see the struct)
     const bool ovl = pl->opt.overlap_calls != 0 && pl->channels == 2 && !pl->resample && !pl->force_generic && !pl->keep_if &&
                      !pl->profiling && pl->opt.pll_mode == 0 && mfma && n_if >= static_cast<size_t>(pl->Hd) &&
                      fe_mfma_available(pl->fe, d_iq, n, hist) && stereo_out_available(p.audio_taps, p.audio_decim);
