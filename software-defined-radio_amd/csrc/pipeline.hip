@@ -652,6 +652,9 @@ int fmrx_pipeline_process(fmrx_pipeline *pl, const uint8_t *iq, size_t n_bytes, 
     const size_t n_au = n_audio_of(pl, n_bytes);
     const size_t nch = pl->channels;
     FMRX_HIP(hipMemcpyAsync(pl->in.p, iq, n_bytes, hipMemcpyHostToDevice, s));
+    // option overlap_calls vouches for inputs that are complete at the call; this one is still on its way: wait for it (the
+    // call ends with a wait anyway, so nothing of the option's gain exists here to lose)
+    if (pl->opt.overlap_calls != 0) FMRX_HIP(hipStreamSynchronize(s));
     FMRX_TRY(fmrx_pipeline_process_dev(pl, pl->in.p, n_bytes, audio_f32 ? pl->out_f32.p : nullptr,
                                        pcm16 ? pl->out_pcm.p : nullptr, pcm_policy, s));
     if (audio_f32) FMRX_HIP(hipMemcpyAsync(audio_f32, pl->out_f32.p, nch * n_au * sizeof(float), hipMemcpyDeviceToHost, s));
