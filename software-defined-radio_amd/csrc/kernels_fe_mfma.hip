@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
             if (audio) *reinterpret_cast<f4 *>(audio + ao) = y;
             if (pcm) {
                 using s4 = short __attribute__((ext_vector_type(4)));
-                const s4 pk = (s4){pcm_pack(y[0], wrap), pcm_pack(y[1], wrap), pcm_pack(y[2], wrap), pcm_pack(y[3], wrap)};
+                const s4 pk = (s4){pcm_pack_flat(y[0], wrap), pcm_pack_flat(y[1], wrap), pcm_pack_flat(y[2], wrap), pcm_pack_flat(y[3], wrap)};   // no branches
                 if (DBG & 131072) __builtin_nontemporal_store(pk, reinterpret_cast<s4 *>(pcm + ao));
                 else *reinterpret_cast<s4 *>(pcm + ao) = pk;
             }

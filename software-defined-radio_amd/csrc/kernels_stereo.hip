@@ -216,7 +216,7 @@ __global__ __launch_bounds__(NT) void stereo_out_kernel(const float *__restrict_
             if (right) right[k] = rr;
             if (pcm) {
                 using s2 = short __attribute__((ext_vector_type(2)));
-                *reinterpret_cast<s2 *>(pcm + 2 * k) = (s2){pcm_pack(l, wrap), pcm_pack(rr, wrap)};
+                *reinterpret_cast<s2 *>(pcm + 2 * k) = (s2){pcm_pack_flat(l, wrap), pcm_pack_flat(rr, wrap)};
             }
         }
     }
