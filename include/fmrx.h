@@ -73,9 +73,18 @@ FMRX_API int fmrx_set_device(int device);
  *   "fe_variant"       0 = matrix-core front-end kernels (default; FMRX_FE_VARIANT=mfma), 1 = vector-ALU kernels (=valu)
  *   "fused_min_audio"  audio samples per call from which the fused mono kernel is used (default 65536; 0 = always)
  *   "resample_l2"      1 = the L2-table resampler kernel also for large calls
+ *   "resample_exact"   1 = the pipeline's resampler (modes 2/3) keeps the reference's rounding sequence (bit-exact kernels) instead
+ *                      of the matrix-core kernel (float32-rounding-equal); the primitive fmrx_resample_fir is always bit-exact
+ *   "resample_chains"  workgroups per XCD and tile group of the matrix-core resampler (0 = as many as are resident; A/B)
+ *   "overlap_calls"    stereo, modes 0/1: 1 (or 2) = the caller vouches that the INPUT of a fmrx_pipeline_process_dev call is
+ *                      complete when the call is made; the stages of consecutive calls then run on internal streams, a call
+ *                      apart (1: the next call's front end under this call's PLL and output stage; 2: three lanes).  Outputs
+ *                      stay complete in the order of the stream passed to the call; results are bit-identical.  Default 0
  *   "fe_wgs_per_cu"    cap on resident workgroups per CU of the front-end kernels (0 = auto)
  *   "pll_warmup", "pll_segment", "pll_head"   lane shape of the parallel-in-time PLL (-1 = built-in)
- *   "pll_align"        1 = lanes of the parallel PLL start on a multiple of the loop's period (default), 0 = exactly pll_warmup early
+ *   "pll_start"        where the parallel PLL's lanes start: 1 (default) = the locked loop solved as a linear system of the
+ *                      input's signs + 64 true steps, 0 = the block's initial state plus drift + 512 true steps
+ *   "pll_align"        1 = lanes of the parallel PLL (pll_start 0) start on a multiple of the loop's period, 0 (default) = exactly pll_warmup early
  *   "pll_mode"         stereo PLL of the specialised pipeline: 0 = parallel in time, fast math (default),
  *                      1 = serial, fast math, 2 = serial, glibc's functions (cause-by-cause variants)
  *   "fused_tune", "fe_mfma_tune"              ablation kernels (timing only, WRONG results): FMRX_EINVAL unless the
@@ -221,7 +230,9 @@ FMRX_API int fmrx_pipeline_process(fmrx_pipeline *pl, const uint8_t *iq, size_t 
                                    int16_t *pcm16, int pcm_policy);
 /* Same, device-resident: d_iq is DEVICE memory (16-byte aligned), outputs are
  * DEVICE memory or NULL; asynchronous on `stream` (a hipStream_t).  This is
- * the entry point the throughput figures are measured on. */
+ * the entry point the throughput figures are measured on.  (With option
+ * "overlap_calls" the input must be complete at the call, not merely ordered
+ * in front of it on `stream`: see the options above.) */
 FMRX_API int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_bytes, float *d_audio_f32,
                                        int16_t *d_pcm16, int pcm_policy, void *stream);
 /* Copies of the last block's device intermediates to host, for parity tests
