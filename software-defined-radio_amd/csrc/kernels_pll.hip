@@ -282,7 +282,7 @@ struct LtiStart {
     double q00, q01, q10, q11, g0, g1;      // Q = A^64; G = one chunk's response to the constant 1
     double f, phi0, iota0, off0, T0;
 };
-__device__ __forceinline__ LtiStart lti_start_setup(const float *in, const float *state, const PllCoef &c)
+__device__ __forceinline__ LtiStart lti_start_setup(const float in0, const float *state, const PllCoef &c)
 {
     LtiStart L;
     L.q00 = c.q00; L.q01 = c.q01; L.q10 = c.q10; L.q11 = c.q11; L.g0 = c.g0; L.g1 = c.g1;
@@ -294,25 +294,43 @@ __device__ __forceinline__ LtiStart lti_start_setup(const float *in, const float
     // the lattice point the detector sees at sample 0: nearest to theta (the float32 trigArg the state stands for)
     const float trig0 = static_cast<float>(c.w * L.off0 + static_cast<double>(state[1]));
     const double th0 = static_cast<double>(trig0) * inv2pi;
-    L.T0 = in[0] > 0.0f ? rint(th0) : rint(th0 - 0.5) + 0.5;
+    L.T0 = in0 > 0.0f ? rint(th0) : rint(th0 - 0.5) + 0.5;
     return L;
 }
-// wg_climb0 = climb of all chunks in front of workgroup wg0 (of 64 chunks); chunk i lies in wg0 or wg0 + 1
-__device__ __forceinline__ void lti_start_state(const LtiStart &L, const double *__restrict__ rec, const double *__restrict__ wgtot,
-                                                long i, long wg0, double wg_climb0, float &integ, float &phase)
+// wg_climb0 = climb of all chunks in front of workgroup wg0 (of 64 chunks); chunk i lies in wg0 or wg0 + 1.
+// The records of the kLtiTerms chunks behind chunk i (lti_fetch) are requested by the caller together with everything else its
+// prologue reads, ahead of the wave's sum of the workgroup totals: one memory round trip instead of four in a row.
+struct LtiRecs {
+    double a[kLtiTerms], b[kLtiTerms], t[kLtiTerms];          // a chunk's zero-state response (2) and the staircase's prefix at its start
+    double tot0, totm;                                         // climb of workgroups wg0 and wg0 - 1
+};
+__device__ __forceinline__ void lti_fetch(LtiRecs &R, const double *__restrict__ rec, const double *__restrict__ wgtot, long i, long wg0)
 {
-    const double tot0 = wgtot[wg0], totm = wg0 > 0 ? wgtot[wg0 - 1] : 0.0;
-    double r0[kLtiTerms], r1[kLtiTerms];
+    R.tot0 = wgtot[wg0];
+    R.totm = wg0 > 0 ? wgtot[wg0 - 1] : 0.0;
 #pragma unroll
     for (int t = 0; t < kLtiTerms; t++) {                     // term t: chunk j = i - (kLtiTerms - t), oldest first
         const long jj = i - (kLtiTerms - t);
         const long j = jj > 0 ? jj : 0;
+        R.a[t] = rec[4 * j + 0];
+        R.b[t] = rec[4 * j + 1];
+        R.t[t] = rec[4 * j + 2];
+    }
+}
+__device__ __forceinline__ void lti_start_state(const LtiStart &L, const LtiRecs &R, long i, long wg0, double wg_climb0, float &integ,
+                                                float &phase)
+{
+    double r0[kLtiTerms], r1[kLtiTerms];
+#pragma unroll
+    for (int t = 0; t < kLtiTerms; t++) {
+        const long jj = i - (kLtiTerms - t);
+        const long j = jj > 0 ? jj : 0;
         const long wj = j / 64;
         // T at the start of chunk j, from its workgroup's base (wg0 - 1, wg0 or wg0 + 1) and its prefix inside it
-        const double wbase = wj == wg0 ? wg_climb0 : (wj > wg0 ? wg_climb0 + tot0 : wg_climb0 - totm);
-        const double base = (L.T0 + wbase + rec[4 * j + 2]) - L.f * (L.off0 + static_cast<double>(j * kLtiChunk)) - L.phi0;
-        r0[t] = rec[4 * j + 0] + base * L.g0;
-        r1[t] = rec[4 * j + 1] + base * L.g1;
+        const double wbase = wj == wg0 ? wg_climb0 : (wj > wg0 ? wg_climb0 + R.tot0 : wg_climb0 - R.totm);
+        const double base = (L.T0 + wbase + R.t[t]) - L.f * (L.off0 + static_cast<double>(j * kLtiChunk)) - L.phi0;
+        r0[t] = R.a[t] + base * L.g0;
+        r1[t] = R.b[t] + base * L.g1;
     }
     double p = 0.0, q = 0.0;
 #pragma unroll
@@ -362,6 +380,9 @@ __device__ __forceinline__ float pll_integ_tol(float base, const float *state, l
 }
 
 // ---- parallel in time -------------------------------------------------------------------------
+// lanes per workgroup of pll_segments_kernel: one wave (256 was measured: 23.1 vs 21.2 us); also what lets a lane keep its
+// chunk records in registers (the register budget of a kernel follows its largest legal workgroup)
+constexpr int kSegThreads = 64;
 // seg[s*16 + 0..5]  state at the END of segment s      (after sample a_s + L - 1; fbI/fbQ/last finished)
 // seg[s*16 + 8..9]  (integ, phase) this lane had at the START of segment s (after its warm-up)
 //
@@ -373,7 +394,7 @@ __device__ __forceinline__ float pll_integ_tol(float base, const float *state, l
 // least W samples early, from the block's initial state plus the drift: its guess is then already within a
 // few grid steps of the true trajectory, and W only has to cover what the drift estimate misses (64
 // samples instead of the 768 it takes to forget a guess that ignores the ripple).  P = 0: no alignment.
-__global__ void pll_segments_kernel(const float *__restrict__ in, long n, float *__restrict__ out,
+__global__ __launch_bounds__(kSegThreads) void pll_segments_kernel(const float *__restrict__ in, long n, float *__restrict__ out,
                                     const float *__restrict__ state, PllCoef c, int L, int W, int P, long nseg,
                                     float *__restrict__ seg, float *hdr, const double *__restrict__ lti_rec,
                                     const double *__restrict__ lti_wgtot, unsigned long long *__restrict__ badmask,
@@ -385,37 +406,58 @@ __global__ void pll_segments_kernel(const float *__restrict__ in, long n, float 
     // the whole wave (its 64 lanes start in that workgroup of 64 chunks or the next one)
     long lti_wg0 = 0;
     double lti_climb0 = 0.0;
+    // Everything the prologue reads is requested here, in one go and in front of the first use of any of it (the wave's sum
+    // of the workgroup totals): the carried state, the block's first sample, this lane's chunk records, its first input
+    // groups.  Lanes past the block read what the last lane reads.
+    const long sgc = sg < nseg ? sg : nseg - 1;
+    const long a = sgc * L;
+    const long b = a + L < n ? a + L : n;
+    long k = 0;
+    if (a > W) {
+        k = a - W;
+        if (P > 0) k -= k % P;
+    }
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 *in4 = reinterpret_cast<const f4 *>(in);
+    const long last4 = (n + 3) / 4 + 1;                   // last group that is safe to read (floats up to n+10)
+    auto grp = [&](long g) { return in4[g < last4 ? g : last4]; };
+    float st[6];
+#pragma unroll
+    for (int u = 0; u < 6; u++) st[u] = state[u];
+    const float in0 = in[0];
+    long g = k / 4;
+    f4 q0 = grp(g), q1 = grp(g + 1), q2 = grp(g + 2);
+    LtiRecs R;
     if (lti_rec) {
         const long a0 = (sg - lane) * L;                       // the wave's first lane
         const long k0 = a0 > W ? a0 - W : 0;
         lti_wg0 = (k0 / kLtiChunk) / 64;
         double part = 0.0;
         // the first 512 totals as 8 loads in flight per lane (a loop of dependent iterations pays a memory round trip each)
+        double tw[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const long u = lane + 64 * r;
-            part += u < lti_wg0 ? lti_wgtot[u] : 0.0;
+            tw[r] = lti_wgtot[u < lti_wg0 ? u : 0];
         }
+        lti_fetch(R, lti_rec, lti_wgtot, k / kLtiChunk, lti_wg0);
+        __builtin_amdgcn_sched_barrier(0);                    // every request above is out before the first sum waits for one
+#pragma unroll
+        for (int r = 0; r < 8; r++) part += lane + 64 * r < lti_wg0 ? tw[r] : 0.0;
         for (long u = lane + 512; u < lti_wg0; u += 64) part += lti_wgtot[u];
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
         lti_climb0 = part;
     }
     if (sg >= nseg) return;
-    const long a = sg * L;
-    const long b = a + L < n ? a + L : n;
-    const PllState s0 = load_state(state);
+    // fr: the angle whose cosine / sine the carried feedback pair is (load_state)
+    const PllState s0{st[0], st[1], st[2], st[3], st[4], st[5], atan2f(st[3], st[2]) * 0.15915494309189533577f};
     PllState s = s0;
-    long k = 0;
-    if (a > W) {
-        k = a - W;
-        if (P > 0) k -= k % P;
-    }
     if (k > 0) {
         if (lti_rec) {
             // the linear system's state in front of sample k (a multiple of 64: host contract)
-            const LtiStart Ls = lti_start_setup(in, state, c);
-            lti_start_state(Ls, lti_rec, lti_wgtot, k / kLtiChunk, lti_wg0, lti_climb0, s.integ, s.phase);
+            const LtiStart Ls = lti_start_setup(in0, st, c);
+            lti_start_state(Ls, R, k / kLtiChunk, lti_wg0, lti_climb0, s.integ, s.phase);
         } else {
             // hdr[5..7] = {phase at the start of the previous call, its length, valid}: the drift
             const float slope = hdr[7] != 0.0f ? (s0.phase - hdr[5]) / hdr[6] : 0.0f;
@@ -430,12 +472,6 @@ __global__ void pll_segments_kernel(const float *__restrict__ in, long n, float 
     // L2 / HBM takes longer than several steps of the chain.  They are fetched as 16-byte groups, three groups
     // (12 samples, ~1 us of chain) ahead.  k, a and L are multiples of 4 and `in` is 16-byte aligned with at
     // least 12 readable floats behind in[n-1] (host contract), so every group is one aligned global_load_dwordx4.
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    const f4 *in4 = reinterpret_cast<const f4 *>(in);
-    const long last4 = (n + 3) / 4 + 1;                   // last group that is safe to read (floats up to n+10)
-    auto grp = [&](long g) { return in4[g < last4 ? g : last4]; };
-    long g = k / 4;
-    f4 q0 = grp(g), q1 = grp(g + 1), q2 = grp(g + 2);
     for (; k < a; k += 4) {                               // warm-up (or exact replay from the block start)
         const f4 cur = q0;
         q0 = q1;
@@ -724,7 +760,6 @@ int k_fm_pll_parallel(const float *d_in, size_t n, float *d_out, float *d_state,
     unsigned *n_repaired = reinterpret_cast<unsigned *>(d_scratch + 2);
     float *seg = d_scratch + 8;
     unsigned long long *badmask = reinterpret_cast<unsigned long long *>(seg + (nseg + 1) * 16);
-    constexpr int kSegThreads = 64;                             // lanes per workgroup of pll_segments_kernel: one wave (256 was measured: 23.1 vs 21.2 us)
     const unsigned grid = static_cast<unsigned>((nseg + kSegThreads - 1) / kSegThreads);
     const double *lti_rec = nullptr, *lti_wgtot = nullptr;
     if (lti) {
