@@ -529,8 +529,8 @@ __global__ __launch_bounds__(kSegThreads) void pll_segments_kernel(const float *
     // its predecessor in another workgroup: pll_repair_kernel judges those (bit 0 of every mask word is left clear).
     // The mask words are written whole: no memset.
     {
-        const float tol_phase = pll_phase_tol(tol_phase_base, state, n, c);
-        const float tol_integ = pll_integ_tol(tol_integ_base, state, n, c);
+        const float tol_phase = pll_phase_tol(tol_phase_base, st, n, c);   // st: the state as fetched in the prologue
+        const float tol_integ = pll_integ_tol(tol_integ_base, st, n, c);
         const float pe_integ = __shfl_up(s.integ, 1, 64), pe_phase = __shfl_up(s.phase, 1, 64);
         bool bad = false;
         float dp = 0.0f, di = 0.0f;
@@ -567,25 +567,42 @@ __global__ __launch_bounds__(kRepairThreads) void pll_repair_kernel(
     unsigned *__restrict__ n_repaired, float *__restrict__ hdr)
 {
     __shared__ int any_todo;
-    const float tol_phase = pll_phase_tol(tol_phase_base, state, n, c);
-    const float tol_integ = pll_integ_tol(tol_integ_base, state, n, c);
-    // the segments whose predecessor ran in another workgroup (every 64th): judged here
     __shared__ int flagged;
-    if (threadIdx.x == 0) flagged = hdr[1] != 0.0f;
+    // Everything the common case (nothing to repair) reads, requested in one go: the state (tolerances, next call's drift
+    // record), the lanes' flag, the diagnostics, this thread's first boundary, the last segment's end state.
+    unsigned *diag = reinterpret_cast<unsigned *>(hdr);
+    const long sg1 = 64 * (1 + static_cast<long>(threadIdx.x));            // the segments whose predecessor ran in another
+    const long sg1c = sg1 < nseg ? sg1 : (nseg > 1 ? nseg - 1 : 1);        // workgroup (every 64th) are judged here
+    float st[6];
+#pragma unroll
+    for (int u = 0; u < 6; u++) st[u] = state[u];
+    const float h1 = hdr[1];
+    const unsigned d3 = diag[3], d4 = diag[4];
+    const float b_integ = seg[sg1c * 16 + 8], b_phase = seg[sg1c * 16 + 9], p_integ = seg[(sg1c - 1) * 16 + 0],
+                p_phase = seg[(sg1c - 1) * 16 + 1];
+    float last[6];
+#pragma unroll
+    for (int u = 0; u < 6; u++) last[u] = seg[(nseg - 1) * 16 + u];
+    __builtin_amdgcn_sched_barrier(0);
+    const float tol_phase = pll_phase_tol(tol_phase_base, st, n, c);
+    const float tol_integ = pll_integ_tol(tol_integ_base, st, n, c);
+    if (threadIdx.x == 0) flagged = h1 != 0.0f;
     __syncthreads();
     {
-        unsigned *diag = reinterpret_cast<unsigned *>(hdr);
-        for (long sg = 64 * (1 + static_cast<long>(threadIdx.x)); sg < nseg; sg += 64 * kRepairThreads) {
-            const float di = fabsf(seg[sg * 16 + 8] - seg[(sg - 1) * 16 + 0]);
-            const float dp = pll_phase_dist(seg[sg * 16 + 9], seg[(sg - 1) * 16 + 1]);
+        auto judge = [&](long sg, float di, float dp) {
             if (!(dp <= tol_phase && di <= tol_integ)) {
                 atomicOr(badmask + sg / 64, 1ull);
                 flagged = 1;
             } else {
-                if (__float_as_uint(dp) > diag[3]) atomicMax(diag + 3, __float_as_uint(dp));
-                if (__float_as_uint(di) > diag[4]) atomicMax(diag + 4, __float_as_uint(di));
+                // the largest accepted differences (diagnostics); compared with the value read above first: an atomic per thread
+                // on two addresses costs more than the rest (a stale smaller value only means an atomic that changes nothing)
+                if (__float_as_uint(dp) > d3) atomicMax(diag + 3, __float_as_uint(dp));
+                if (__float_as_uint(di) > d4) atomicMax(diag + 4, __float_as_uint(di));
             }
-        }
+        };
+        if (sg1 < nseg) judge(sg1, fabsf(b_integ - p_integ), pll_phase_dist(b_phase, p_phase));
+        for (long sg = sg1 + 64 * kRepairThreads; sg < nseg; sg += 64 * kRepairThreads)
+            judge(sg, fabsf(seg[sg * 16 + 8] - seg[(sg - 1) * 16 + 0]), pll_phase_dist(seg[sg * 16 + 9], seg[(sg - 1) * 16 + 1]));
     }
     __threadfence_block();
     __syncthreads();
@@ -635,11 +652,16 @@ __global__ __launch_bounds__(kRepairThreads) void pll_repair_kernel(
     if (threadIdx.x == 0) {
         // remember where this call's phase started, for the next call's extrapolation (pll_start = 0)
         hdr[1] = 0.0f;                                         // for the next call's lanes to raise again
-        hdr[5] = state[1];
+        hdr[5] = st[1];
         hdr[6] = static_cast<float>(n);
         hdr[7] = 1.0f;
-        PllState e = load_state(seg + (nseg - 1) * 16);
-        store_state(state, e);
+        if (nothing_to_do) {                                   // the last segment's end state as fetched above
+#pragma unroll
+            for (int u = 0; u < 6; u++) state[u] = last[u];
+        } else {
+            PllState e = load_state(seg + (nseg - 1) * 16);
+            store_state(state, e);
+        }
     }
 }
 
