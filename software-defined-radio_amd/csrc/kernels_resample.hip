@@ -28,7 +28,8 @@
 // every U outputs = D inputs, so 16 consecutive outputs (rows) x 16 consecutive periods (columns) share one
 // banded tap matrix: a 16x16 output tile is  A[16 x K] * X[K x 16]  on the f32 matrix cores
 // (v_mfma_f32_16x16x4_f32), K = the inputs the 16 rows touch (15*D/U + J, 186 / 212 for modes 2 / 3), A resident
-// in registers, X = the periods' input windows staged once per workgroup in LDS.  Per output ~190 MACs are issued
+// in registers, X = the periods' input windows staged in LDS, block of 16 periods after block (a workgroup walks several:
+// taps loaded once, the next block fetched under the current block's products).  Per output ~190 MACs are issued
 // instead of 101, but as 1/64 of a matrix instruction instead of a dependent chain with two LDS gathers per MAC.
 // The sum is an fma chain over the window (newest sample first, like the reference's j ascending) instead of
 // separately rounded products and sums: equal to float32 rounding (1e-7), not bit for bit.
