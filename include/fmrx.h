@@ -306,6 +306,22 @@ FMRX_API int fmrx_pipeline_set_option(fmrx_pipeline *pl, const char *name, long 
  *   Output: [n_channels][n_audio] float and/or s16, n_audio = fmrx_channels_n_audio(). */
 typedef struct fmrx_channels fmrx_channels;
 FMRX_API int fmrx_channels_create(fmrx_channels **out, const fmrx_params *p, int n_channels, size_t block_bytes, int device);
+/* The same bank with the two choices the reference's command line has (src/project.cpp:390-419: <mode> <channels>) and the
+ * numerics mode spelled out:
+ *   audio_channels  1 = mono (RF_MONO, src/project.cpp:311-382), 2 = stereo (RF_STEREO, :154-309)
+ *   exact           1 = every stage in the reference's float32 evaluation order and fmPLL (src/filter.cpp:32-80) as the
+ *                   serial recurrence with glibc's sinf / cosf / atan2f, ONE LANE PER CHANNEL (64 receivers per wave):
+ *                   audio is the compiled reference's bit for bit, per channel, for any stream length.  This is the way
+ *                   to run stereo within the 1e-4 bound at speed: the recurrence cannot be cut in time without leaving
+ *                   the reference's trajectory, but receivers are independent (one STATES set
+ *                   each, src/project.cpp:455-468).
+ *                   0 = the specialised kernels (fmrx_channels_create's; mono only).
+ * Outputs: audio_f32 [n_channels][audio_channels][n_audio] (stereo: left, then right), pcm16
+ * [n_channels][n_audio][audio_channels] (stereo: interleaved L,R as the writer at src/project.cpp:292-302). */
+FMRX_API int fmrx_channels_create_ex(fmrx_channels **out, const fmrx_params *p, int n_channels, int audio_channels, int exact,
+                                     size_t block_bytes, int device);
+/* exact banks: one channel's intermediates of the last call (FMRX_TAP_DEMOD, _CARRIER, _STEREO_BPF, _PLL [n_if + 1]) */
+FMRX_API int fmrx_channels_read_tap(fmrx_channels *c, int channel, int which, float *out, size_t *n);
 FMRX_API int fmrx_channels_destroy(fmrx_channels *c);
 FMRX_API size_t fmrx_channels_n_audio(const fmrx_channels *c);
 FMRX_API int fmrx_channels_input_layout(const fmrx_channels *c, uint8_t **d_first_block, size_t *pitch_bytes);

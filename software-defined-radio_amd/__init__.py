@@ -115,6 +115,8 @@ _sig("fmrx_pipeline_set_keep_intermediates", [_vp, _int])
 _sig("fmrx_pipeline_set_option", [_vp, C.c_char_p, C.c_long])
 _sig("fmrx_pipeline_pll_diagnostics", [_vp, C.POINTER(_uint), C.POINTER(_flt), C.POINTER(_flt)])
 _sig("fmrx_channels_create", [C.POINTER(_vp), C.POINTER(Params), _int, _sz, _int])
+_sig("fmrx_channels_create_ex", [C.POINTER(_vp), C.POINTER(Params), _int, _int, _int, _sz, _int])
+_sig("fmrx_channels_read_tap", [_vp, _int, _int, _vp, C.POINTER(_sz)])
 _sig("fmrx_channels_destroy", [_vp])
 _sig("fmrx_channels_n_audio", [_vp], _sz)
 _sig("fmrx_channels_input_layout", [_vp, C.POINTER(_vp), C.POINTER(_sz)])
@@ -468,14 +470,22 @@ class Pipeline:
 
 
 class Channels:
-    """N independent mono channels (modes 0/1), the current block of all of them in one device call (fmrx_channels_*)."""
+    """N independent receivers (modes 0/1), the current block of all of them in one device call (fmrx_channels_*).
 
-    def __init__(self, mode=0, n_channels=1, rf_taps=101, base_audio_taps=101, block_bytes=None, device=0, params: Params | None = None):
-        self.params = params if params is not None else modeParams(mode, rf_taps, base_audio_taps, 101)
+    audio_channels: 1 mono, 2 stereo (the reference's second command-line argument).  exact=True: every stage in the
+    reference's float32 evaluation order, fmPLL as the serial recurrence with glibc's functions, one lane per channel --
+    audio equals the compiled reference's bit for bit (stereo banks are always exact)."""
+
+    def __init__(self, mode=0, n_channels=1, rf_taps=101, base_audio_taps=101, block_bytes=None, device=0, params: Params | None = None,
+                 audio_channels=1, exact=False, stereo_taps=101):
+        self.params = params if params is not None else modeParams(mode, rf_taps, base_audio_taps, stereo_taps)
         self.n_channels = int(n_channels)
+        self.audio_channels = int(audio_channels)
+        self.exact = bool(exact)
         self.block_bytes = int(block_bytes or self.params.block_bytes)
         self._h = _vp()
-        _check(lib.fmrx_channels_create(C.byref(self._h), C.byref(self.params), self.n_channels, self.block_bytes, device))
+        _check(lib.fmrx_channels_create_ex(C.byref(self._h), C.byref(self.params), self.n_channels, self.audio_channels,
+                                           int(self.exact), self.block_bytes, device))
         self.n_audio = lib.fmrx_channels_n_audio(self._h)
 
     def close(self):
@@ -497,11 +507,24 @@ class Channels:
     def process(self, iq_u8, want_pcm=True, wrap=True):
         """iq_u8: [n_channels, block_bytes] uint8 (host) -> dict(audio=[n_channels, n_audio] f32, pcm16=... s16)."""
         iq = _u8(iq_u8).reshape(self.n_channels, self.block_bytes)
-        f = np.zeros((self.n_channels, self.n_audio), np.float32)
-        s = np.zeros((self.n_channels, self.n_audio), np.int16) if want_pcm else None
+        st = self.audio_channels == 2
+        f = np.zeros((self.n_channels, 2, self.n_audio) if st else (self.n_channels, self.n_audio), np.float32)
+        s = None
+        if want_pcm:
+            s = np.zeros((self.n_channels, self.n_audio, 2) if st else (self.n_channels, self.n_audio), np.int16)
         _check(lib.fmrx_channels_process(self._h, iq.reshape(-1), f.ctypes.data, s.ctypes.data if want_pcm else None,
                                          PCM_WRAP if wrap else PCM_SATURATE))
+        if st:   # stereo: audio [n_channels, 2, n_audio] (left, right), pcm16 [n_channels, n_audio, 2] interleaved L,R
+            return {"audio": f, "audio_l": f[:, 0], "audio_r": f[:, 1], "pcm16": s}
         return {"audio": f, "pcm16": s}
+
+    def read_tap(self, channel, name) -> np.ndarray:
+        """Exact banks: one channel's intermediate of the last call ('demod', 'carrier_filt', 'stereo_filt', 'pll')."""
+        n = _sz(0)
+        _check(lib.fmrx_channels_read_tap(self._h, channel, TAPS[name], None, C.byref(n)))
+        out = np.zeros(n.value, np.float32)
+        _check(lib.fmrx_channels_read_tap(self._h, channel, TAPS[name], out.ctypes.data, C.byref(n)))
+        return out
 
     def load_dev(self, d_iq_ptr, stream=None):
         """Device-resident [n_channels, block_bytes] blocks -> the channels' slots (async on `stream`)."""

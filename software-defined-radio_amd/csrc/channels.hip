@@ -37,6 +37,9 @@ struct fmrx_channels {
     DevBuf<float> zeros, audio_all;
     DevBuf<int16_t> pcm_all, pcm_out;
     DevBuf<float> f32_out;
+    // banks in the reference's evaluation order, and every stereo bank: channels_stereo.hip
+    int audio_channels = 1, exact = 0;
+    StereoBank *bank = nullptr;
 };
 
 namespace {
@@ -83,8 +86,47 @@ extern "C" {
 
 int fmrx_channels_create(fmrx_channels **out, const fmrx_params *p, int n_channels, size_t block_bytes, int device)
 {
+    return fmrx_channels_create_ex(out, p, n_channels, 1, 0, block_bytes, device);
+}
+
+int fmrx_channels_create_ex(fmrx_channels **out, const fmrx_params *p, int n_channels, int audio_channels, int exact,
+                            size_t block_bytes, int device)
+{
     if (!out || !p) return fail(FMRX_EINVAL, "channels_create: null argument");
     if (n_channels < 1) return fail(FMRX_EINVAL, "channels_create: n_channels must be >= 1");
+    if (audio_channels != 1 && audio_channels != 2) return fail(FMRX_EINVAL, "channels_create: audio_channels must be 1 (mono) or 2 (stereo)");
+    if (audio_channels == 2 || exact) {
+        if (p->audio_upsamp != 0) return fail(FMRX_EINVAL, "channels_create: the batched entry point covers the integer-decimation modes (0, 1)");
+        const size_t unit4 = static_cast<size_t>(2) * p->rf_decim * p->audio_decim;
+        if (block_bytes == 0 || block_bytes % unit4 || block_bytes % 16)
+            return fail(FMRX_EINVAL, "channels_create: block_bytes must be a multiple of 16 and of 2*rf_decim*audio_decim = %zu", unit4);
+        if (!exact) return fail(FMRX_EINVAL, "channels_create: stereo banks run in the reference's evaluation order (exact = 1)");
+        FMRX_TRY(require_device());
+        FMRX_HIP(hipSetDevice(device));
+        fmrx_channels *c = new fmrx_channels;
+        c->p = *p;
+        c->n_channels = n_channels;
+        c->device = device;
+        c->block_bytes = block_bytes;
+        c->audio_channels = audio_channels;
+        c->exact = 1;
+        c->opt = default_options();
+        auto body = [&]() -> int {
+            FMRX_TRY(stereo_bank_create(&c->bank, *p, n_channels, audio_channels, block_bytes));
+            c->n_audio = stereo_bank_n_audio(c->bank);
+            FMRX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+            FMRX_TRY(c->pcm_out.alloc(c->n_audio * n_channels * audio_channels));
+            FMRX_TRY(c->f32_out.alloc(c->n_audio * n_channels * audio_channels));
+            return FMRX_OK;
+        };
+        const int rc = body();
+        if (rc != FMRX_OK) {
+            fmrx_channels_destroy(c);
+            return rc;
+        }
+        *out = c;
+        return FMRX_OK;
+    }
     if (p->audio_upsamp != 0) return fail(FMRX_EINVAL, "channels_create: the batched entry point covers the integer-decimation modes (0, 1)");
     const size_t unit = static_cast<size_t>(2) * p->rf_decim * p->audio_decim;
     if (block_bytes == 0 || block_bytes % unit || block_bytes % 16)
@@ -149,6 +191,10 @@ int fmrx_channels_destroy(fmrx_channels *c)
         (void)hipStreamSynchronize(c->stream);
         (void)hipStreamDestroy(c->stream);
     }
+    if (c->bank) {
+        (void)hipDeviceSynchronize();
+        stereo_bank_destroy(c->bank);
+    }
     delete c;
     return FMRX_OK;
 }
@@ -158,6 +204,11 @@ size_t fmrx_channels_n_audio(const fmrx_channels *c) { return c ? c->n_audio : 0
 int fmrx_channels_input_layout(const fmrx_channels *c, uint8_t **d_first_block, size_t *pitch_bytes)
 {
     if (!c || !d_first_block || !pitch_bytes) return fail(FMRX_EINVAL, "channels_input_layout: null argument");
+    if (c->bank) {
+        *d_first_block = stereo_bank_first_block(c->bank);
+        *pitch_bytes = stereo_bank_pitch(c->bank);
+        return FMRX_OK;
+    }
     *d_first_block = c->slots.p + c->hist_bytes;
     *pitch_bytes = c->slot_bytes;
     return FMRX_OK;
@@ -168,6 +219,7 @@ int fmrx_channels_reset(fmrx_channels *c, int channel)
     if (!c) return fail(FMRX_EINVAL, "channels_reset: null handle");
     if (channel >= c->n_channels) return fail(FMRX_EINVAL, "channels_reset: channel %d of %d", channel, c->n_channels);
     FMRX_HIP(hipSetDevice(c->device));
+    if (c->bank) return stereo_bank_reset(c->bank, channel);
     FMRX_HIP(hipDeviceSynchronize());
     if (channel < 0) return k_fill_u8(c->slots.p, c->slot_bytes * c->n_channels, 128, nullptr);
     return k_fill_u8(c->slots.p + static_cast<size_t>(channel) * c->slot_bytes, c->hist_bytes, 128, nullptr);
@@ -178,6 +230,7 @@ int fmrx_channels_process_dev(fmrx_channels *c, float *d_audio_f32, int16_t *d_p
     if (!c) return fail(FMRX_EINVAL, "channels_process_dev: null handle");
     FMRX_HIP(hipSetDevice(c->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (c->bank) return stereo_bank_process_dev(c->bank, d_audio_f32, d_pcm16, pcm_policy, s);
     const size_t total = c->slot_bytes * c->n_channels;
     const float *zend = c->zeros.p + c->p.audio_taps + 32;     // "one past the previous block's last discriminator sample": zeros
     FMRX_TRY(mono_fused_launch(c->fe, c->audio, c->slots.p, total / 2, c->fe.silence.p, c->zeros.p, zend, nullptr, 0, nullptr,
@@ -197,8 +250,14 @@ int fmrx_channels_load_dev(fmrx_channels *c, const uint8_t *d_iq, void *stream)
 {
     if (!c || !d_iq) return fail(FMRX_EINVAL, "channels_load_dev: null argument");
     FMRX_HIP(hipSetDevice(c->device));
-    FMRX_HIP(hipMemcpy2DAsync(c->slots.p + c->hist_bytes, c->slot_bytes, d_iq, c->block_bytes, c->block_bytes, c->n_channels,
-                              hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    uint8_t *first = c->slots.p + c->hist_bytes;
+    size_t pitch = c->slot_bytes;
+    if (c->bank) {
+        first = stereo_bank_first_block(c->bank);
+        pitch = stereo_bank_pitch(c->bank);
+    }
+    FMRX_HIP(hipMemcpy2DAsync(first, pitch, d_iq, c->block_bytes, c->block_bytes, c->n_channels, hipMemcpyDeviceToDevice,
+                              static_cast<hipStream_t>(stream)));
     return FMRX_OK;
 }
 
@@ -208,14 +267,27 @@ int fmrx_channels_process(fmrx_channels *c, const uint8_t *iq, float *audio_f32,
     FMRX_HIP(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     // channel-major host array [n_channels][block_bytes] -> the block region of every slot: one strided copy
-    FMRX_HIP(hipMemcpy2DAsync(c->slots.p + c->hist_bytes, c->slot_bytes, iq, c->block_bytes, c->block_bytes, c->n_channels,
-                              hipMemcpyHostToDevice, s));
+    uint8_t *first = c->slots.p + c->hist_bytes;
+    size_t pitch = c->slot_bytes;
+    if (c->bank) {
+        first = stereo_bank_first_block(c->bank);
+        pitch = stereo_bank_pitch(c->bank);
+    }
+    FMRX_HIP(hipMemcpy2DAsync(first, pitch, iq, c->block_bytes, c->block_bytes, c->n_channels, hipMemcpyHostToDevice, s));
     FMRX_TRY(fmrx_channels_process_dev(c, audio_f32 ? c->f32_out.p : nullptr, pcm16 ? c->pcm_out.p : nullptr, pcm_policy, s));
-    const size_t n = c->n_audio * c->n_channels;
+    const size_t n = c->n_audio * c->n_channels * c->audio_channels;
     if (audio_f32) FMRX_HIP(hipMemcpyAsync(audio_f32, c->f32_out.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
     if (pcm16) FMRX_HIP(hipMemcpyAsync(pcm16, c->pcm_out.p, n * sizeof(int16_t), hipMemcpyDeviceToHost, s));
     FMRX_HIP(hipStreamSynchronize(s));
     return FMRX_OK;
+}
+
+int fmrx_channels_read_tap(fmrx_channels *c, int channel, int which, float *out, size_t *n)
+{
+    if (!c || !n) return fail(FMRX_EINVAL, "channels_read_tap: null argument");
+    if (!c->bank) return fail(FMRX_EINVAL, "channels_read_tap: only banks created with exact = 1 keep their intermediates in memory");
+    FMRX_HIP(hipSetDevice(c->device));
+    return stereo_bank_read_tap(c->bank, channel, which, out, n);
 }
 
 }  // extern "C"

@@ -263,6 +263,9 @@ int k_fm_pll_parallel(const float *d_in, size_t n, float *d_out, float *d_state,
 // d_lti: where the chunk records live (pll_parallel_lti_floats(n) floats, 8-byte aligned) if not inside d_scratch -- a caller
 // that runs phase 1 of its next call on another stream while phase 2 of this one reads them keeps two
 size_t pll_parallel_lti_floats(size_t n);
+// many channels, lane = channel, the exact serial recurrence (kernels_pll.hip); rows [channel][pitch], state 8 floats per channel
+int k_fm_pll_channels(const float *d_in, long pitch_in, size_t n, int n_ch, float *d_trig, long pitch_trig, float *d_state,
+                      float *d_nco0, float freq, float Fs, float ncoScale, float phaseAdjust, float normBandwidth, hipStream_t s);
 int k_mix(const float *d_bpf, const float *d_pll, size_t n, float *d_mix, hipStream_t s);
 int k_combine(const float *d_st, const float *d_mono, size_t n, float *d_l, float *d_r, hipStream_t s);
 int k_upsample(const float *d_x, size_t n, float *d_xu, int up, hipStream_t s);
@@ -277,6 +280,18 @@ int k_stream_read(const void *d_buf, size_t bytes, int method, unsigned *d_sink,
 // ---- diagnostics (kernels_psd.hip) ---------------------------------------------------
 // d_seg_db: (n/nfft)*(nfft/2) floats of scratch; d_freq, d_psd: nfft/2 floats
 int k_estimate_psd(const float *d_x, size_t n, float Fs, int nfft, float *d_seg_db, float *d_freq, float *d_psd, hipStream_t s);
+
+// ---- banks of receivers in the reference's evaluation order (channels_stereo.hip) ----
+struct StereoBank;
+bool stereo_bank_supported(const fmrx_params &p, int audio_channels);
+int stereo_bank_create(StereoBank **out, const fmrx_params &p, int n_channels, int audio_channels, size_t block_bytes);
+void stereo_bank_destroy(StereoBank *b);
+size_t stereo_bank_n_audio(const StereoBank *b);
+uint8_t *stereo_bank_first_block(const StereoBank *b);
+size_t stereo_bank_pitch(const StereoBank *b);
+int stereo_bank_reset(StereoBank *b, int channel);
+int stereo_bank_process_dev(StereoBank *b, float *d_audio, int16_t *d_pcm, int wrap, hipStream_t s);
+int stereo_bank_read_tap(StereoBank *b, int channel, int which, float *out, size_t *n);
 
 // ---- host-side coefficient design (coeff.cpp) --------------------------------
 void design_lpf(float Fs, float Fc, int taps, float *h);

@@ -665,6 +665,50 @@ __global__ __launch_bounds__(kRepairThreads) void pll_repair_kernel(
     }
 }
 
+// ---- many channels: lane = channel, every lane the EXACT serial recurrence ---------------------------------------
+// The recurrence cannot be cut in time without leaving the reference's trajectory, but channels are independent
+// (one STATES set per receiver, src/project.cpp:455-468): a wave walks 64 channels' loops in lock step, the bank's
+// rows are [channel][sample].  in: the pilot band-pass output; trig: the raw trigArg of every step (the NCO output
+// cosf(trigArg*ncoScale + phaseAdjust) is off the chain: the bank's output kernel applies it); state: 8 floats per
+// channel, the reference's six first; nco0[channel] = PLL[0] of this call = the incoming state's lastOut.
+// Rows are 16-byte aligned with >= 16 readable floats behind their n samples (host contract): the input is fetched as
+// 16-byte groups three groups ahead of the chain.
+template <int MATH>
+__global__ __launch_bounds__(64) void pll_channels_kernel(const float *__restrict__ in, long pitch_in, long n, long n_ch,
+                                                           float *__restrict__ trig, long pitch_trig, float *__restrict__ state,
+                                                           float *__restrict__ nco0, PllCoef c)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const long ch = static_cast<long>(blockIdx.x) * 64 + threadIdx.x;
+    if (ch >= n_ch) return;
+    float *st = state + 8 * ch;
+    PllState s{st[0], st[1], st[2], st[3], st[4], st[5], 0.0f};
+    if (MATH == kFast) s.fr = atan2f(st[3], st[2]) * 0.15915494309189533577f;
+    nco0[ch] = s.last;
+    const f4 *in4 = reinterpret_cast<const f4 *>(in + ch * pitch_in);
+    f4 *out4 = reinterpret_cast<f4 *>(trig + ch * pitch_trig);
+    const long ng = n / 4;
+    f4 q0 = in4[0], q1 = in4[1], q2 = in4[2];
+    for (long g = 0; g < ng; g++) {
+        const f4 cur = q0;
+        q0 = q1;
+        q1 = q2;
+        q2 = in4[g + 3];
+        f4 r;
+        pll_step<MATH>(s, cur.x, c); r.x = s.last;
+        pll_step<MATH>(s, cur.y, c); r.y = s.last;
+        pll_step<MATH>(s, cur.z, c); r.z = s.last;
+        pll_step<MATH>(s, cur.w, c); r.w = s.last;
+        out4[g] = r;
+    }
+    for (long k = 4 * ng, i = 0; k < n; k++, i++) {          // a block that is not a multiple of four samples
+        pll_step<MATH>(s, q0[i], c);
+        trig[ch * pitch_trig + k] = s.last;
+    }
+    finish_state<MATH>(s, c);
+    store_state(st, s);
+}
+
 __global__ void libm_eval_kernel(int fn, const float *__restrict__ a, const float *__restrict__ b, size_t n,
                                  float *__restrict__ out)
 {
@@ -717,6 +761,20 @@ int k_fm_pll(const float *d_in, size_t n, float *d_out, float *d_state, float fr
         if (n) hipLaunchKernelGGL(nco_out_kernel<kExact>, dim3(grid), dim3(256), 0, s, d_out, n, c);
     }
     FMRX_LAUNCH_CHECK("nco_out");
+    return FMRX_OK;
+}
+
+int k_fm_pll_channels(const float *d_in, long pitch_in, size_t n, int n_ch, float *d_trig, long pitch_trig, float *d_state,
+                      float *d_nco0, float freq, float Fs, float ncoScale, float phaseAdjust, float normBandwidth, hipStream_t s)
+{
+    if (n == 0 || n_ch <= 0) return FMRX_OK;
+    if (reinterpret_cast<uintptr_t>(d_in) % 16 || reinterpret_cast<uintptr_t>(d_trig) % 16 || pitch_in % 4 || pitch_trig % 4 ||
+        pitch_in < static_cast<long>(n) + 16)
+        return fail(FMRX_EINVAL, "fm_pll_channels: rows must be 16-byte aligned with 16 readable floats behind their samples");
+    const PllCoef c = make_coef(freq, Fs, ncoScale, phaseAdjust, normBandwidth);
+    hipLaunchKernelGGL(pll_channels_kernel<kExact>, dim3(static_cast<unsigned>((n_ch + 63) / 64)), dim3(64), 0, s, d_in, pitch_in,
+                       static_cast<long>(n), static_cast<long>(n_ch), d_trig, pitch_trig, d_state, d_nco0, c);
+    FMRX_LAUNCH_CHECK("pll_channels");
     return FMRX_OK;
 }
 

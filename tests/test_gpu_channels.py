@@ -1,0 +1,153 @@
+"""GPU parity tests of the receiver banks (fmrx_channels_create_ex: N independent receivers per device call,
+src/project.cpp:455-468 has one STATES set per receiver), through the C ABI.
+
+Exact banks (exact = 1) promise the compiled reference's audio BIT FOR BIT per channel: every comparison below is on
+bit patterns, against the oracle (oracle/fm_oracle.c, itself pinned bit for bit to the compiled reference) and, for the
+golden fixture's stream, against the compiled reference's own SHA-256 (tests/golden/stereo_long_mode0.npz).
+"""
+import hashlib
+import os
+from concurrent.futures import ProcessPoolExecutor
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def bits_equal(a, b, msg=""):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape, msg)
+    if a.dtype == np.float32:
+        a, b = a.view(np.uint32), b.view(np.uint32)
+    np.testing.assert_array_equal(a, b, err_msg=msg)
+
+
+def channel_stream(oracle, c, n_samples, rf_Fs):
+    """Channel c's synthetic stream: its own dither seed and its own place in the programme (the generator's seed only
+    drives the dither; the start offset moves the tones and the pilot's phase)."""
+    return oracle.synth_fm_u8(n_samples, rf_Fs=rf_Fs, seed=0x3D74 + c, start=0 if c == 0 else 7919 * c)
+
+
+@pytest.mark.parametrize("mode,taps", [(0, (101, 101, 101)), (1, (101, 101, 101)), (0, (151, 101, 151)), (0, (13, 13, 13))])
+def test_stereo_bank_exact(fmrx, oracle, mode, taps):
+    """Five stereo receivers, four reference-size blocks each, every intermediate of every channel against the oracle
+    streaming that channel alone: discriminator output, both band-pass outputs, NCO, left, right -- all bit for bit;
+    PCM equal.  Then one channel is reset (a new stream starts there) while the others carry on."""
+    p = oracle.mode_params(mode, *taps)
+    N, nblk, bb = 5, 4, p.block_bytes
+    streams = [channel_stream(oracle, c, bb // 2 * (nblk + 2), p.rf_Fs) for c in range(N)]
+    ch = fmrx.Channels(mode, N, rf_taps=taps[0], base_audio_taps=taps[1], stereo_taps=taps[2], audio_channels=2, exact=True)
+    refs = [oracle.pipeline(mode, 2, *taps) for _ in range(N)]
+    assert ch.n_audio == 1024
+
+    def check(b, channels):
+        iq = np.stack([st[b * bb:(b + 1) * bb] for st in streams])
+        out = ch.process(iq)
+        for c in channels:
+            want = refs[c].process(streams[c][b * bb:(b + 1) * bb])
+            tag = f"mode {mode} taps {taps} channel {c} block {b}"
+            bits_equal(ch.read_tap(c, "demod"), want["demod"], "demod " + tag)
+            bits_equal(ch.read_tap(c, "carrier_filt"), refs[c].intermediate("carrier_filt"), "pilot band-pass " + tag)
+            bits_equal(ch.read_tap(c, "stereo_filt"), refs[c].intermediate("stereo_filt"), "22-54 kHz band-pass " + tag)
+            bits_equal(ch.read_tap(c, "pll"), refs[c].intermediate("pll"), "NCO " + tag)
+            bits_equal(out["audio_l"][c], want["audio_l"], "left " + tag)
+            bits_equal(out["audio_r"][c], want["audio_r"], "right " + tag)
+            bits_equal(out["pcm16"][c, :, 0], oracle.pcm16(want["audio_l"]), "pcm left " + tag)
+            bits_equal(out["pcm16"][c, :, 1], oracle.pcm16(want["audio_r"]), "pcm right " + tag)
+
+    for b in range(nblk):
+        check(b, range(N))
+    ch.reset(3)
+    refs[3] = oracle.pipeline(mode, 2, *taps)
+    for b in range(nblk, nblk + 2):
+        check(b, range(N))
+
+
+def test_mono_bank_exact(fmrx, oracle):
+    """The mono bank in the reference's evaluation order: audio bit for bit (the specialised mono bank promises 2e-6)."""
+    for mode in (0, 1):
+        p = oracle.mode_params(mode, 101, 101, 101)
+        N, nblk, bb = 3, 3, p.block_bytes
+        streams = [channel_stream(oracle, c, bb // 2 * nblk, p.rf_Fs) for c in range(N)]
+        ch = fmrx.Channels(mode, N, exact=True)
+        refs = [oracle.pipeline(mode, 1) for _ in range(N)]
+        for b in range(nblk):
+            out = ch.process(np.stack([st[b * bb:(b + 1) * bb] for st in streams]))
+            for c in range(N):
+                want = refs[c].process(streams[c][b * bb:(b + 1) * bb])["audio"]
+                bits_equal(out["audio"][c], want, f"mode {mode} channel {c} block {b}")
+                bits_equal(out["pcm16"][c], oracle.pcm16(want))
+
+
+def test_bank_other_block_sizes(fmrx, oracle):
+    """Blocks that are not the reference's size: ragged against the kernels' tiles (504 IF outputs per wave, 2048 per
+    band-pass workgroup, 512 audio outputs per workgroup), several times the reference's, and the smallest the bank
+    accepts; the oracle consumes the same stream in the same cuts."""
+    p = oracle.mode_params(0, 101, 101, 101)
+    for bb in (102400 * 3, 2 * 10 * 5 * 8 * 63, 8000):
+        N = 3
+        streams = [channel_stream(oracle, 10 + c, bb // 2 * 3, p.rf_Fs) for c in range(N)]
+        ch = fmrx.Channels(0, N, audio_channels=2, exact=True, block_bytes=bb)
+        refs = [oracle.pipeline(0, 2) for _ in range(N)]
+        for b in range(3):
+            out = ch.process(np.stack([st[b * bb:(b + 1) * bb] for st in streams]))
+            for c in range(N):
+                want = refs[c].process(streams[c][b * bb:(b + 1) * bb])
+                bits_equal(out["audio_l"][c], want["audio_l"], f"block_bytes {bb} channel {c} block {b}")
+                bits_equal(out["audio_r"][c], want["audio_r"])
+    with pytest.raises(fmrx.FmrxError):
+        fmrx.Channels(0, 4, audio_channels=2, exact=True, block_bytes=1600)      # shorter than the history a channel carries
+    with pytest.raises(fmrx.FmrxError):
+        fmrx.Channels(2, 4, audio_channels=2, exact=True)                        # resampling modes: not in the bank
+    with pytest.raises(fmrx.FmrxError):
+        fmrx.Channels(0, 4, audio_channels=2, exact=False)                       # stereo banks are exact
+
+
+def _oracle_channel(args):
+    """Worker: channel c's stream and the oracle's left / right over it (CPU, one process per channel)."""
+    c, nblk, bb, rf_Fs = args
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    if here not in sys.path:
+        sys.path.insert(0, here)
+    from _oracle import Oracle
+    o = Oracle()
+    iq = channel_stream(o, c, bb // 2 * nblk, rf_Fs)
+    pl = o.pipeline(0, 2)
+    L, R = [], []
+    for b in range(nblk):
+        out = pl.process(iq[b * bb:(b + 1) * bb])
+        L.append(out["audio_l"]); R.append(out["audio_r"])
+    return c, iq, np.concatenate(L), np.concatenate(R)
+
+
+def test_stereo_bank_exact_256_channels_two_seconds(fmrx, oracle):
+    """256 stereo receivers with distinct signals, 100 reference blocks = 2.13 s of stream each, one bank, one call per
+    block period: left and right of EVERY channel equal the oracle's bit for bit over the whole stream -- far beyond
+    the 0.13 s after which any re-ordered implementation has left the reference's PLL trajectory.
+    Channel 0 carries the stream of tests/golden/stereo_long_mode0.npz: its output must also hash to the COMPILED
+    REFERENCE's SHA-256 (nothing from the oracle involved)."""
+    g = np.load(os.path.join(G, "stereo_long_mode0.npz"))
+    p = oracle.mode_params(0, 101, 101, 101)
+    N, nblk, bb = 256, int(g["nblk"][0]), p.block_bytes
+    assert int(g["seed"][0]) == 0x3D74 and nblk * bb // 2 / p.rf_Fs > 2.0
+    with ProcessPoolExecutor(max_workers=min(12, os.cpu_count() or 1)) as ex:
+        res = sorted(ex.map(_oracle_channel, [(c, nblk, bb, float(p.rf_Fs)) for c in range(N)], chunksize=4), key=lambda r: r[0])
+    assert hashlib.sha256(res[0][1].tobytes()).digest() == g["iq_sha256"].tobytes()
+    ch = fmrx.Channels(0, N, audio_channels=2, exact=True)
+    L = np.zeros((N, nblk * 1024), np.float32)
+    R = np.zeros((N, nblk * 1024), np.float32)
+    for b in range(nblk):
+        out = ch.process(np.stack([r[1][b * bb:(b + 1) * bb] for r in res]), want_pcm=False)
+        L[:, b * 1024:(b + 1) * 1024] = out["audio_l"]
+        R[:, b * 1024:(b + 1) * 1024] = out["audio_r"]
+    for c in range(N):
+        bits_equal(L[c], res[c][2], f"left, channel {c}")
+        bits_equal(R[c], res[c][3], f"right, channel {c}")
+    assert hashlib.sha256(L[0].tobytes()).digest() == g["audio_l_sha256"].tobytes()
+    assert hashlib.sha256(R[0].tobytes()).digest() == g["audio_r_sha256"].tobytes()
+    # the signals really are different receivers' (not 256 copies)
+    assert len({hashlib.sha256(L[c].tobytes()).digest() for c in range(N)}) == N
