@@ -164,7 +164,8 @@ FMRX_API int fmrx_pcm16(const float *audio, size_t n, int16_t *out, int wrap);
 /* ------------------------------------------------------------------ */
 /* out[i] = sinf(a[i]) (fn 0), cosf(a[i]) (fn 1) or atan2f(a[i], b[i]) (fn 2) as the DEVICE evaluates the
  * restatement of glibc 2.35's functions that fmPLL uses (csrc/glibc_libm.hpp): lets a test compare the
- * device build with the C library of the host, bit for bit.  b may be NULL for fn 0, 1. */
+ * device build with the C library of the host, bit for bit.  b may be NULL for fn 0, 1.  fn 3, 4, 5: the same three
+ * through the branch-free forms the receiver banks' PLL lanes run (general function where those are not defined). */
 FMRX_API int fmrx_diag_libm(int fn, const float *a, const float *b, size_t n, float *out);
 /* Measurement aid for bench.py: ONE pure streaming read of a device buffer (>= 3 MiB, 16-byte aligned) by
  * one of the access methods the front-end kernels use -- method 0: non-temporal global loads into

@@ -196,13 +196,14 @@ def diagStreamRead(d_ptr, n_bytes, method=0, stream=None) -> None:
     _check(lib.fmrx_diag_stream_read_dev(d_ptr, n_bytes, method, stream))
 
 
-def deviceLibm(fn: str, a, b=None) -> np.ndarray:
-    """sinf / cosf / atan2f as the device evaluates csrc/glibc_libm.hpp (fmrx_diag_libm): test hook."""
+def deviceLibm(fn: str, a, b=None, flat=False) -> np.ndarray:
+    """sinf / cosf / atan2f as the device evaluates csrc/glibc_libm.hpp (fmrx_diag_libm): test hook.
+    flat: through the branch-free forms the receiver banks' PLL lanes run."""
     a = _f32(a)
     out = np.zeros(len(a), np.float32)
     bb = _f32(b) if b is not None else None
-    _check(lib.fmrx_diag_libm({"sinf": 0, "cosf": 1, "atan2f": 2}[fn], a, bb.ctypes.data if bb is not None else None,
-                              len(a), out))
+    _check(lib.fmrx_diag_libm({"sinf": 0, "cosf": 1, "atan2f": 2}[fn] + (3 if flat else 0), a,
+                              bb.ctypes.data if bb is not None else None, len(a), out))
     return out
 
 

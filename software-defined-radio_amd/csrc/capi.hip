@@ -450,15 +450,15 @@ int fmrx_stereo_combine(const float *stereo_final, const float *mono, size_t n, 
 // ---- diagnostics ---------------------------------------------------------------------------
 int fmrx_diag_libm(int fn, const float *a, const float *b, size_t n, float *out)
 {
-    if (fn < 0 || fn > 2) return fail(FMRX_EINVAL, "diag_libm: fn must be 0 (sinf), 1 (cosf) or 2 (atan2f)");
-    if ((!a || !out || (fn == 2 && !b)) && n) return fail(FMRX_EINVAL, "diag_libm: null buffer");
+    if (fn < 0 || fn > 5) return fail(FMRX_EINVAL, "diag_libm: fn must be 0 (sinf), 1 (cosf), 2 (atan2f) or 3..5 (their branch-free forms)");
+    if ((!a || !out || (fn % 3 == 2 && !b)) && n) return fail(FMRX_EINVAL, "diag_libm: null buffer");
     FMRX_TRY(require_device());
     Scratch &s = scratch();
     FMRX_TRY(s.a.ensure(n));
     FMRX_TRY(s.b.ensure(n));
     FMRX_TRY(s.c.ensure(n));
     FMRX_TRY(h2d(s.a.p, a, n * sizeof(float)));
-    if (fn == 2) FMRX_TRY(h2d(s.b.p, b, n * sizeof(float)));
+    if (fn % 3 == 2) FMRX_TRY(h2d(s.b.p, b, n * sizeof(float)));
     FMRX_TRY(k_libm_eval(fn, s.a.p, s.b.p, n, s.c.p, nullptr));
     return d2h(out, s.c.p, n * sizeof(float));
 }

@@ -265,7 +265,8 @@ int k_fm_pll_parallel(const float *d_in, size_t n, float *d_out, float *d_state,
 size_t pll_parallel_lti_floats(size_t n);
 // many channels, lane = channel, the exact serial recurrence (kernels_pll.hip); rows [channel][pitch], state 8 floats per channel
 int k_fm_pll_channels(const float *d_in, long pitch_in, size_t n, int n_ch, float *d_trig, long pitch_trig, float *d_state,
-                      float *d_nco0, float freq, float Fs, float ncoScale, float phaseAdjust, float normBandwidth, hipStream_t s);
+                      float *d_nco0, float freq, float Fs, float ncoScale, float phaseAdjust, float normBandwidth, hipStream_t s,
+                      bool flat = true);   // flat: the branch-free forms of glibc's functions (same values; false = A/B)
 int k_mix(const float *d_bpf, const float *d_pll, size_t n, float *d_mix, hipStream_t s);
 int k_combine(const float *d_st, const float *d_mono, size_t n, float *d_l, float *d_r, hipStream_t s);
 int k_upsample(const float *d_x, size_t n, float *d_xu, int up, hipStream_t s);

@@ -297,5 +297,96 @@ FMRX_HD float atan2f_glibc(float y, float x)
     }
 }
 
+// ---- the same functions without control flow, for the common arguments ---------------------------------------
+// A wave that walks 64 receivers' PLLs (kernels_pll.hip: pll_channels_kernel) has every lane in another branch of the
+// functions above -- five argument ranges in atanf, four quadrants in atan2f, sine / cosine polynomial by quadrant --
+// and pays for all of them.  These variants compute the same value by the same float operations, with every choice
+// a select.  They are defined for the ordinary arguments only (*_ok); the caller sends the whole wave through
+// the general functions when any lane holds anything else.  Pinned like the functions above: libm_check.cpp
+// compares them with the C library over the same argument sets.
+FMRX_HD bool atan2f_flat_ok(float y, float x)
+{
+    const uint32_t hx = f2u(x), ix = hx & 0x7fffffffu, iy = f2u(y) & 0x7fffffffu;
+    // finite and non-zero, both; x == 1 takes atanf(y) in the original, a different sequence of operations
+    return ix - 1u < 0x7f7fffffu && iy - 1u < 0x7f7fffffu && hx != 0x3f800000u;
+}
+
+FMRX_HD float atan2f_flat(float y, float x)
+{
+    const float pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    const float hi0 = 4.6364760399e-01f, hi1 = 7.8539812565e-01f, hi2 = 9.8279368877e-01f, hi3 = 1.5707962513e+00f;
+    const float lo0 = 5.0121582440e-09f, lo1 = 3.7748947079e-08f, lo2 = 3.4473217170e-08f, lo3 = 7.5497894159e-08f;
+    const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f, aT3 = -1.1111110449e-01f,
+                aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f, aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f,
+                aT8 = 4.9768779427e-02f, aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
+    const uint32_t hx = f2u(x), hy = f2u(y);
+    const int k = (static_cast<int>(hy & 0x7fffffffu) - static_cast<int>(hx & 0x7fffffffu)) >> 23;
+    const float q = u2f(f2u(y / x) & 0x7fffffffu);             // fabsf(y/x): one IEEE divide
+    // atanf(q), q >= 0 (possibly 0 or +inf after the division)
+    const uint32_t iq = f2u(q);
+    const bool big = iq >= 0x4c000000u, small = iq < 0x3ee00000u, tiny = iq < 0x31000000u;
+    const bool r0 = iq < 0x3f300000u, r1 = iq < 0x3f980000u, r2 = iq < 0x401c0000u;
+    const float n0 = 2.0f * q - 1.0f, d0 = 2.0f + q;
+    const float n1 = q - 1.0f, d1 = q + 1.0f;
+    const float n2 = q - 1.5f, d2 = 1.0f + 1.5f * q;
+    const float num = small ? q : r0 ? n0 : r1 ? n1 : r2 ? n2 : -1.0f;
+    const float den = small ? 1.0f : r0 ? d0 : r1 ? d1 : r2 ? d2 : q;
+    const float hi = r0 ? hi0 : r1 ? hi1 : r2 ? hi2 : hi3;
+    const float lo = r0 ? lo0 : r1 ? lo1 : r2 ? lo2 : lo3;
+    const float xr = num / den;                                // the range's reduced argument (q itself below 7/16: q / 1)
+    const float z2 = xr * xr;
+    const float w = z2 * z2;
+    const float s1 = z2 * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    const float ps = xr * (s1 + s2);
+    const float res_small = xr - ps;
+    const float res_range = hi - ((ps - lo) - xr);
+    float z = small ? (tiny ? q : res_small) : res_range;
+    z = big ? hi3 + lo3 : z;
+    z = k > 60 ? pi_o_2 + 0.5f * pi_lo : (((hx >> 31) && k < -60) ? 0.0f : z);
+    const float t = z - pi_lo;
+    const float zneg = u2f(f2u(z) ^ 0x80000000u);
+    const bool xneg = (hx >> 31) != 0, yneg = (hy >> 31) != 0;
+    return xneg ? (yneg ? t - pi : pi - t) : (yneg ? zneg : z);
+}
+
+// 4/pi in the 24 windows reduce_large can ask for (inv_pio4(0..23)); a device kernel keeps the table in LDS
+FMRX_HD void inv_pio4_table(uint32_t *w24)
+{
+    for (int i = 0; i < 24; i++) w24[i] = inv_pio4(i);
+}
+
+FMRX_HD bool sincosf_large_ok(float y)
+{
+    const uint32_t top = (f2u(y) >> 20) & 0x7ffu;
+    return top >= 0x42fu && top < 0x7f8u;                      // 120 <= |y| < inf
+}
+
+FMRX_HD void sincosf_large_flat(float y, const uint32_t *w24, float *sn, float *cs)
+{
+    const uint32_t xi = f2u(y);
+    const int idx = static_cast<int>((xi >> 26) & 15);
+    const int shift = static_cast<int>((xi >> 23) & 7);
+    uint32_t m = (xi & 0xffffffu) | 0x800000u;
+    m <<= shift;
+    uint64_t res0 = static_cast<uint32_t>(m * w24[idx]);
+    const uint64_t res1 = static_cast<uint64_t>(m) * w24[idx + 4];
+    const uint64_t res2 = static_cast<uint64_t>(m) * w24[idx + 8];
+    res0 = (res2 >> 32) | (res0 << 32);
+    res0 += res1;
+    const uint64_t n = (res0 + (1ull << 61)) >> 62;
+    res0 -= n << 62;
+    const double rx = static_cast<double>(static_cast<int64_t>(res0)) * kPi63;
+    const int rn = static_cast<int>(n);
+    const int mq = rn + static_cast<int>(xi >> 31);
+    const double x2 = rx * rx;
+    const double xs = ((mq + 1) & 2) ? -rx : rx;
+    const float sp = sin_poly(xs, x2);
+    const float cp0 = cos_poly(x2);
+    const float cp = (mq & 2) ? -cp0 : cp0;
+    *sn = (rn & 1) ? cp : sp;
+    *cs = (rn & 1) ? sp : cp;
+}
+
 }  // namespace glibc235
 }  // namespace fmrx

@@ -118,6 +118,28 @@ __device__ __forceinline__ void pll_step(PllState &s, float v, const PllCoef &c)
     s.last = trigArg;
 }
 
+// The exact step without control flow, for a wave whose lanes are different receivers (pll_channels_kernel): the same float
+// operations as pll_step<kExact>, every choice inside atan2f / sincosf a select (glibc_libm.hpp: *_flat, pinned against the C
+// library like the originals).  Those variants cover the ordinary arguments -- finite non-zero phase-detector inputs, |trigArg|
+// >= 120 (every sample of a stream but its first 240) --; one wave-uniform test each sends the whole wave through the general
+// functions when any lane holds anything else (silence, a drop-out, a stream that has just started).  w24: 4/pi's 24 windows, in LDS.
+__device__ __forceinline__ void pll_step_exact_flat(PllState &s, float v, const PllCoef &c, const uint32_t *w24)
+{
+    const float eI = v * s.fbI;
+    const float eQ = v * (-1 * s.fbQ);
+    float eD;
+    if (__builtin_expect(!__any(!glibc235::atan2f_flat_ok(eQ, eI)), 1)) eD = glibc235::atan2f_flat(eQ, eI);
+    else eD = glibc235::atan2f_glibc(eQ, eI);
+    s.integ = s.integ + c.Ki * eD;
+    const float pe = c.Kp * eD;
+    s.phase = (s.phase + pe) + s.integ;
+    s.off += 1;
+    const float trigArg = static_cast<float>(c.w * static_cast<double>(s.off) + static_cast<double>(s.phase));
+    if (__builtin_expect(!__any(!glibc235::sincosf_large_ok(trigArg)), 1)) glibc235::sincosf_large_flat(trigArg, w24, &s.fbQ, &s.fbI);
+    else glibc235::sincosf_glibc(trigArg, &s.fbQ, &s.fbI);
+    s.last = trigArg;
+}
+
 // The fast step for an ordinary sample (|v| in (1e-20, 1e20): everything but exact zeros, denormal products and
 // non-finite values), without a branch: what the lanes of the parallel form run.  Identical arithmetic to
 // pll_step<kFast>'s closed-form path; written with selects so that the recurrence's critical path holds no
@@ -673,12 +695,15 @@ __global__ __launch_bounds__(kRepairThreads) void pll_repair_kernel(
 // channel, the reference's six first; nco0[channel] = PLL[0] of this call = the incoming state's lastOut.
 // Rows are 16-byte aligned with >= 16 readable floats behind their n samples (host contract): the input is fetched as
 // 16-byte groups three groups ahead of the chain.
-template <int MATH>
+template <int MATH, bool FLAT>
 __global__ __launch_bounds__(64) void pll_channels_kernel(const float *__restrict__ in, long pitch_in, long n, long n_ch,
                                                            float *__restrict__ trig, long pitch_trig, float *__restrict__ state,
                                                            float *__restrict__ nco0, PllCoef c)
 {
     typedef float f4 __attribute__((ext_vector_type(4)));
+    __shared__ uint32_t w24[24];
+    if (threadIdx.x < 24) w24[threadIdx.x] = glibc235::inv_pio4(threadIdx.x);
+    __syncthreads();
     const long ch = static_cast<long>(blockIdx.x) * 64 + threadIdx.x;
     if (ch >= n_ch) return;
     float *st = state + 8 * ch;
@@ -695,10 +720,17 @@ __global__ __launch_bounds__(64) void pll_channels_kernel(const float *__restric
         q1 = q2;
         q2 = in4[g + 3];
         f4 r;
-        pll_step<MATH>(s, cur.x, c); r.x = s.last;
-        pll_step<MATH>(s, cur.y, c); r.y = s.last;
-        pll_step<MATH>(s, cur.z, c); r.z = s.last;
-        pll_step<MATH>(s, cur.w, c); r.w = s.last;
+        if (MATH == kExact && FLAT) {
+            pll_step_exact_flat(s, cur.x, c, w24); r.x = s.last;
+            pll_step_exact_flat(s, cur.y, c, w24); r.y = s.last;
+            pll_step_exact_flat(s, cur.z, c, w24); r.z = s.last;
+            pll_step_exact_flat(s, cur.w, c, w24); r.w = s.last;
+        } else {
+            pll_step<MATH>(s, cur.x, c); r.x = s.last;
+            pll_step<MATH>(s, cur.y, c); r.y = s.last;
+            pll_step<MATH>(s, cur.z, c); r.z = s.last;
+            pll_step<MATH>(s, cur.w, c); r.w = s.last;
+        }
         out4[g] = r;
     }
     for (long k = 4 * ng, i = 0; k < n; k++, i++) {          // a block that is not a multiple of four samples
@@ -714,7 +746,21 @@ __global__ void libm_eval_kernel(int fn, const float *__restrict__ a, const floa
 {
     const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    out[i] = fn == 0 ? glibc235::sinf_glibc(a[i]) : fn == 1 ? glibc235::cosf_glibc(a[i]) : glibc235::atan2f_glibc(a[i], b[i]);
+    if (fn <= 2) {
+        out[i] = fn == 0 ? glibc235::sinf_glibc(a[i]) : fn == 1 ? glibc235::cosf_glibc(a[i]) : glibc235::atan2f_glibc(a[i], b[i]);
+        return;
+    }
+    // 3, 4, 5: the branch-free variants where they are defined (the general function elsewhere: what a wave of the bank's PLL does)
+    uint32_t w24[24];
+    glibc235::inv_pio4_table(w24);
+    if (fn == 5) {
+        out[i] = glibc235::atan2f_flat_ok(a[i], b[i]) ? glibc235::atan2f_flat(a[i], b[i]) : glibc235::atan2f_glibc(a[i], b[i]);
+    } else {
+        float sn, cs;
+        if (glibc235::sincosf_large_ok(a[i])) glibc235::sincosf_large_flat(a[i], w24, &sn, &cs);
+        else glibc235::sincosf_glibc(a[i], &sn, &cs);
+        out[i] = fn == 3 ? sn : cs;
+    }
 }
 
 PllCoef make_coef(float freq, float Fs, float ncoScale, float phaseAdjust, float normBandwidth)
@@ -765,15 +811,19 @@ int k_fm_pll(const float *d_in, size_t n, float *d_out, float *d_state, float fr
 }
 
 int k_fm_pll_channels(const float *d_in, long pitch_in, size_t n, int n_ch, float *d_trig, long pitch_trig, float *d_state,
-                      float *d_nco0, float freq, float Fs, float ncoScale, float phaseAdjust, float normBandwidth, hipStream_t s)
+                      float *d_nco0, float freq, float Fs, float ncoScale, float phaseAdjust, float normBandwidth, hipStream_t s, bool flat)
 {
     if (n == 0 || n_ch <= 0) return FMRX_OK;
     if (reinterpret_cast<uintptr_t>(d_in) % 16 || reinterpret_cast<uintptr_t>(d_trig) % 16 || pitch_in % 4 || pitch_trig % 4 ||
         pitch_in < static_cast<long>(n) + 16)
         return fail(FMRX_EINVAL, "fm_pll_channels: rows must be 16-byte aligned with 16 readable floats behind their samples");
     const PllCoef c = make_coef(freq, Fs, ncoScale, phaseAdjust, normBandwidth);
-    hipLaunchKernelGGL(pll_channels_kernel<kExact>, dim3(static_cast<unsigned>((n_ch + 63) / 64)), dim3(64), 0, s, d_in, pitch_in,
-                       static_cast<long>(n), static_cast<long>(n_ch), d_trig, pitch_trig, d_state, d_nco0, c);
+    if (flat)
+        hipLaunchKernelGGL((pll_channels_kernel<kExact, true>), dim3(static_cast<unsigned>((n_ch + 63) / 64)), dim3(64), 0, s, d_in, pitch_in,
+                           static_cast<long>(n), static_cast<long>(n_ch), d_trig, pitch_trig, d_state, d_nco0, c);
+    else
+        hipLaunchKernelGGL((pll_channels_kernel<kExact, false>), dim3(static_cast<unsigned>((n_ch + 63) / 64)), dim3(64), 0, s, d_in, pitch_in,
+                           static_cast<long>(n), static_cast<long>(n_ch), d_trig, pitch_trig, d_state, d_nco0, c);
     FMRX_LAUNCH_CHECK("pll_channels");
     return FMRX_OK;
 }

@@ -26,6 +26,7 @@ static bool same(float a, float b)
 }
 
 static std::atomic<uint64_t> bad_s{0}, bad_c{0}, bad_a{0}, shown{0};
+static std::atomic<uint64_t> flat_sc{0}, flat_a{0};   // arguments that also went through the branch-free variants
 
 static void report(const char *what, float x, float y, float got, float want)
 {
@@ -42,6 +43,9 @@ int main(int argc, char **argv)
         const uint64_t first = std::strtoull(argv[2], nullptr, 0), count = std::strtoull(argv[3], nullptr, 0);
         for (unsigned t = 0; t < nt; t++)
             th.emplace_back([=] {
+                uint32_t w24[24];
+                inv_pio4_table(w24);
+                uint64_t nflat = 0;
                 for (uint64_t i = first + t; i < first + count; i += nt) {
                     const float x = u2f(static_cast<uint32_t>(i));
                     float s, c;
@@ -49,11 +53,19 @@ int main(int argc, char **argv)
                     const float ws = sinf(x), wc = cosf(x);
                     if (!same(s, ws)) { bad_s++; report("sinf", x, 0, s, ws); }
                     if (!same(c, wc)) { bad_c++; report("cosf", x, 0, c, wc); }
+                    if (sincosf_large_ok(x)) {               // the branch-free variant, wherever it is defined
+                        sincosf_large_flat(x, w24, &s, &c);
+                        if (!same(s, ws)) { bad_s++; report("sinf (flat)", x, 0, s, ws); }
+                        if (!same(c, wc)) { bad_c++; report("cosf (flat)", x, 0, c, wc); }
+                        nflat++;
+                    }
                 }
+                flat_sc += nflat;
             });
         for (auto &t : th) t.join();
         printf("sinf checked %" PRIu64 " mismatches %" PRIu64 "\ncosf checked %" PRIu64 " mismatches %" PRIu64 "\n", count,
                bad_s.load(), count, bad_c.load());
+        printf("branch-free sincosf checked %" PRIu64 "\n", flat_sc.load());
         return bad_s || bad_c ? 1 : 0;
     }
     if (!std::strcmp(argv[1], "atan2")) {
@@ -63,9 +75,15 @@ int main(int argc, char **argv)
             th.emplace_back([=, &n] {
                 std::mt19937_64 g(seed + 7919 * t);
                 uint64_t done = 0;
+                uint64_t nflat = 0;
                 auto chk = [&](float y, float x) {
                     const float got = atan2f_glibc(y, x), want = atan2f(y, x);
                     if (!same(got, want)) { bad_a++; report("atan2f", y, x, got, want); }
+                    if (atan2f_flat_ok(y, x)) {              // the branch-free variant, wherever it is defined
+                        const float gf = atan2f_flat(y, x);
+                        if (!same(gf, want)) { bad_a++; report("atan2f (flat)", y, x, gf, want); }
+                        nflat++;
+                    }
                     done++;
                 };
                 for (uint64_t i = t; i < pairs; i += nt) {
@@ -101,9 +119,11 @@ int main(int argc, char **argv)
                         for (float x : sp) chk(y, x);
                 }
                 n += done;
+                flat_a += nflat;
             });
         for (auto &t : th) t.join();
         printf("atan2f checked %" PRIu64 " mismatches %" PRIu64 "\n", n.load(), bad_a.load());
+        printf("branch-free atan2f checked %" PRIu64 "\n", flat_a.load());
         return bad_a ? 1 : 0;
     }
     return 2;

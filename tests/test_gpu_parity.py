@@ -218,9 +218,11 @@ def test_device_libm_is_glibc(fmrx, oracle):
                         (rng.random(1 << 22) * 8388608.0).astype(np.float32),
                         np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 0.75, 120.0, 119.99999, 0.7499999, 2.0**-12, 3.4e38], np.float32)])
     for fn in ("sinf", "cosf"):
-        got, want = fmrx.deviceLibm(fn, x), oracle.libm(fn, x)
-        ok = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
-        assert ok.all(), (fn, x[~ok][:5], got[~ok][:5], want[~ok][:5])
+        want = oracle.libm(fn, x)
+        for flat in (False, True):   # flat: the branch-free forms the receiver banks' PLL lanes run (same values by construction)
+            got = fmrx.deviceLibm(fn, x, flat=flat)
+            ok = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+            assert ok.all(), (fn, flat, x[~ok][:5], got[~ok][:5], want[~ok][:5])
     t = (rng.random(1 << 22) * 500000.0).astype(np.float32)
     v = (rng.standard_normal(1 << 22) * 10.0 ** rng.integers(-9, 1, 1 << 22)).astype(np.float32)
     y1, x1 = v * (-1 * oracle.libm("sinf", t)), v * oracle.libm("cosf", t)
@@ -231,9 +233,11 @@ def test_device_libm_is_glibc(fmrx, oracle):
     sp = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 3.4e38, 1e-30, 1e30], np.float32)
     ys = np.concatenate([y1, y2, q * x3, np.repeat(sp, len(sp))])
     xs = np.concatenate([x1, x2, x3, np.tile(sp, len(sp))])
-    got, want = fmrx.deviceLibm("atan2f", ys, xs), oracle.libm("atan2f", ys, xs)
-    ok = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
-    assert ok.all(), (ys[~ok][:5], xs[~ok][:5], got[~ok][:5], want[~ok][:5])
+    want = oracle.libm("atan2f", ys, xs)
+    for flat in (False, True):
+        got = fmrx.deviceLibm("atan2f", ys, xs, flat=flat)
+        ok = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+        assert ok.all(), (flat, ys[~ok][:5], xs[~ok][:5], got[~ok][:5], want[~ok][:5])
 
 
 def test_pll_stage(fmrx, oracle):

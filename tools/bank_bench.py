@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Receiver-bank timing (fmrx_channels_create_ex): N channels, one block each per call, inputs resident in HBM.
+  python3 tools/bank_bench.py [--channels 1024,4096,...] [--audio-channels 2] [--exact 1] [--blocks-per-call 1] [--calls 5]
+Prints one line per N: ms per call, MS/s, fraction of the HBM peak on the algorithmic bytes (2 + 4/50 = 2.08 B per
+sample for stereo s16).  Run under rocprofv3 --kernel-trace --stats for the per-kernel split."""
+import argparse, importlib, os, sys, time
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+fmrx = importlib.import_module("software-defined-radio_amd")
+synth = importlib.import_module("software-defined-radio_amd.synth")
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--channels", default="1024,4096,16384")
+ap.add_argument("--audio-channels", type=int, default=2)
+ap.add_argument("--exact", type=int, default=1)
+ap.add_argument("--mode", type=int, default=0)
+ap.add_argument("--blocks-per-call", type=int, default=1, help="reference-size blocks per channel and call")
+ap.add_argument("--calls", type=int, default=5)
+ap.add_argument("--distinct", type=int, default=64, help="distinct signals dealt round-robin over the channels")
+a = ap.parse_args()
+
+p = fmrx.modeParams(a.mode)
+bb = p.block_bytes * a.blocks_per_call
+ns = bb // 2
+base = [torch.from_numpy(synth.synth_fm_u8(ns, float(p.rf_Fs), seed=0x3D74 + c, start=7919 * c)) for c in range(a.distinct)]
+base = torch.stack(base).cuda()                                 # [distinct, bb]
+stream = torch.cuda.current_stream().cuda_stream
+for nch in [int(x) for x in a.channels.split(",")]:
+    chs = fmrx.Channels(a.mode, nch, audio_channels=a.audio_channels, exact=bool(a.exact), block_bytes=bb)
+    reps = (nch + a.distinct - 1) // a.distinct
+    src = base.repeat(reps, 1)[:nch].contiguous()
+    chs.load_dev(src.data_ptr(), stream)
+    del src
+    d_pcm = torch.empty(nch * chs.n_audio * a.audio_channels, dtype=torch.int16, device="cuda")
+    for _ in range(2):
+        chs.process_dev(None, d_pcm.data_ptr(), wrap=True, stream=stream)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.calls):
+        chs.process_dev(None, d_pcm.data_ptr(), wrap=True, stream=stream)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / a.calls
+    samples = nch * ns
+    bps = 2 + 2 * a.audio_channels / (p.rf_decim * p.audio_decim)
+    print(f"channels {nch:6d} x {ns} samples: {ms:9.3f} ms/call  {samples / ms / 1e3:10.1f} MS/s  "
+          f"{samples * bps / (ms * 1e-3) / 8e12:6.4f} of HBM peak  ({nch * (ns / p.rf_Fs) / (ms * 1e-3):9.0f} channels at real time)", flush=True)
+    chs.close()
+    del d_pcm
+    torch.cuda.empty_cache()
