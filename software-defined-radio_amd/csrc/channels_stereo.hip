@@ -14,7 +14,8 @@
 //   chs_fe_exact_kernel      u8 I/Q -> (u-128)/128 -> rf FIR -> decimate -> discriminator   (src/project.cpp:82-128)
 //   chs_bpf_exact_kernel     both band-pass filters of the stereo path in one pass           (:202, :207)
 //   pll_channels_kernel      fmPLL, lane = channel (kernels_pll.hip)                          (:237)
-//   chs_out_kernel           NCO cosine, mixer, both audio FIRs, L/R, PCM                     (:246-302)
+//   chs_nco_exact_kernel     the NCO output's cosine, off the recurrence's chain              (src/filter.cpp:72)
+//   chs_out_exact_kernel     mixer, both audio FIRs, L/R, PCM                                 (:246-302)
 //   chs_finish_kernel        carried state: every row's tail -> its history
 //
 // "Exact" means the reference's float32 operations in the reference's order -- separately rounded products and
@@ -28,7 +29,7 @@
 // Data layout: everything is channel-major rows with the carried history in front:
 //   slots   u8  [n_channels][hist_bytes | block_bytes]   raw I/Q as on stdin; the history IS I_state/Q_state/prev_i/prev_q
 //   demod   f32 [n_channels][Hd | n_if | pad]            discriminator output; history = state_mono / _stereo / _carrier / _allpass
-//   carrier, bpf, trig f32 [n_channels][n_if + pad]      pilot band-pass, 22-54 kHz band-pass, raw trigArg of every PLL step
+//   carrier, bpf, trig f32 [n_channels][n_if + pad]      pilot band-pass, 22-54 kHz band-pass, raw trigArg of every PLL step -> NCO output
 //   pll     f32 [n_channels][8]                          state_PLL (6) ; nco0 [n_channels] = PLL[0] of this call
 //   mixtail f32 [2][n_channels][Hm]                      state_stereofilt, ping-pong
 #include "device_math.hpp"
@@ -131,9 +132,12 @@ __device__ __forceinline__ void fex_step(const uint32_t (&raw)[FeX<T, D>::NB * 4
 // One wave per tile of 63*R outputs of one channel; lane 0 recomputes the R outputs in front of the tile (from the
 // history in front of the block for the first tile) only to hand IF[k0-1] to lane 1: every IF sample is produced by
 // the same instruction sequence wherever it is computed.
+// Workgroups are single waves in all three wide kernels: a stereo call runs them next to the PLL's lanes (one long-lived wave
+// per CU that keeps its SIMD's vector ALU nearly busy and, being the oldest wave there, wins every issue slot it wants); a
+// workgroup of four waves would hold its slot until its wave on that SIMD is through (measured: 2.2 x the kernel time).
 template <int T, int D>
-__global__ __launch_bounds__(256) void chs_fe_exact_kernel(const uint8_t *__restrict__ slots, long slot_bytes, int hist_bytes,
-                                                            long n_if, long ntiles, long wgs_per_channel,
+__global__ __launch_bounds__(64) void chs_fe_exact_kernel(const uint8_t *__restrict__ slots, long slot_bytes, int hist_bytes,
+                                                            long k_lo, long n_if, long ntiles, long wgs_per_channel,
                                                             const float *__restrict__ table, float *__restrict__ demod,
                                                             long dpitch, int Hd)
 {
@@ -141,10 +145,10 @@ __global__ __launch_bounds__(256) void chs_fe_exact_kernel(const uint8_t *__rest
     constexpr int R = kR;
     const int lane = threadIdx.x & 63;
     const long c = blockIdx.x / wgs_per_channel;
-    const long tile = (blockIdx.x % wgs_per_channel) * 4 + (threadIdx.x >> 6);
+    const long tile = blockIdx.x % wgs_per_channel;
     if (tile >= ntiles) return;                                  // wave-uniform
     const uint8_t *blk = slots + c * slot_bytes + hist_bytes;
-    const long k0 = tile * C::TILE + static_cast<long>(lane - 1) * R;
+    const long k0 = k_lo + tile * C::TILE + static_cast<long>(lane - 1) * R;   // outputs [k_lo, n_if) of the block: this launch's share
     const long w0 = k0 * D - (T - 1) - C::LEAD;                  // first sample of the 16-byte aligned window
     const u4 *src = reinterpret_cast<const u4 *>(blk + 2 * w0);
     uint32_t raw[C::NB * 4];
@@ -229,14 +233,14 @@ __device__ __forceinline__ void bpx_step(const float (&w)[BpX<T>::NW], const flo
 }
 
 template <int T>
-__global__ __launch_bounds__(256) void chs_bpf_exact_kernel(const float *__restrict__ demod, long dpitch, int Hd, long n_if,
+__global__ __launch_bounds__(64) void chs_bpf_exact_kernel(const float *__restrict__ demod, long dpitch, int Hd, long k_lo, long n_if,
                                                              long wgs_per_channel, const float *__restrict__ table,
                                                              float *__restrict__ y_st, float *__restrict__ y_car, long ypitch)
 {
     using C = BpX<T>;
     constexpr int R = kR;
     const long c = blockIdx.x / wgs_per_channel;
-    const long k0 = ((blockIdx.x % wgs_per_channel) * 256 + threadIdx.x) * R;
+    const long k0 = k_lo + ((blockIdx.x % wgs_per_channel) * 64 + threadIdx.x) * R;
     if (k0 >= n_if) return;
     const float *x = demod + c * dpitch + Hd;
     const f4 *src = reinterpret_cast<const f4 *>(x + k0 - (T - 1) - C::LEAD);
@@ -271,121 +275,229 @@ __global__ __launch_bounds__(256) void chs_bpf_exact_kernel(const float *__restr
     }
 }
 
-// ---- everything behind the PLL ------------------------------------------------------------------------------------
-// The NCO output cosf(trigArg*ncoScale + phaseAdjust) (src/filter.cpp:72; off the recurrence's chain), the mixer
-// (src/project.cpp:246-248), the two audio convolveBlockFastFIR calls of RF_STEREO -- mono branch on the all-passed
-// discriminator output (:194, :219), stereo branch on the mixer output (:257) --, the L/R combine (:277-280) and the
-// interleaved PCM writer (:292-302).  A workgroup stages the window of its NT*R audio outputs as (mono, mixer)
-// pairs in LDS (the mixer products and the cosines are formed while staging and never go to HBM); the two FIRs share
-// the taps, so they ride in the two halves of the packed instructions.  EXACT: glibc's cosf, products and sums rounded
-// separately, taps ascending; otherwise one fma per tap and the hardware cosine (the fast bank).
-// Mono banks (STEREO = false) run the same kernel with the mixer half compiled out.
-template <int T, int D, int R, int NT, bool EXACT, bool STEREO>
-__global__ __launch_bounds__(NT) void chs_out_kernel(const float *__restrict__ demod, long dpitch, int Hd, const float *__restrict__ bpf,
-                                                      const float *__restrict__ trig, long ypitch, const float *__restrict__ nco0,
-                                                      const float *__restrict__ mix_tail_in, float *__restrict__ mix_tail_out, int hm,
-                                                      long n_if, int delay, float nco_scale, float phase_adjust,
-                                                      const float *__restrict__ h, long wgs_per_channel, float *__restrict__ audio,
-                                                      int16_t *__restrict__ pcm, int wrap, long n_out)
+// ---- the NCO output ----------------------------------------------------------------------------------------------------
+// PLL[k+1] = cosf(trigArg[k]*ncoScale + phaseAdjust) (src/filter.cpp:72) is not on the recurrence's chain: the lanes leave the
+// raw trigArg of every step, this kernel turns a chunk's row segment into finished NCO values in place, four per thread
+// (glibc's cosf: the branch-free form when the whole wave's arguments are ordinary, i.e. always but in a stream's first 120 samples).
+__global__ __launch_bounds__(256) void chs_nco_exact_kernel(float *__restrict__ trig, long ypitch, long k_lo, long k_hi, long wgs_per_channel,
+                                                             float nco_scale, float phase_adjust)
 {
-    constexpr int NOUT = NT * R;
-    constexpr int WL = D * (NOUT - 1) + T;
-    extern __shared__ f2 win[];
-    const int t = threadIdx.x;
+    __shared__ uint32_t w24[24];
+    if (threadIdx.x < 24) w24[threadIdx.x] = glibc235::inv_pio4(threadIdx.x);
+    __syncthreads();
     const long c = blockIdx.x / wgs_per_channel;
-    const long a0 = (blockIdx.x % wgs_per_channel) * NOUT;
-    const long g0 = D * a0 - (T - 1);                      // IF index of window sample 0
-    const float *dm = demod + c * dpitch + Hd;
-    const float *bp = STEREO ? bpf + c * ypitch : nullptr, *tr = STEREO ? trig + c * ypitch : nullptr;
-    const float *tin = STEREO ? mix_tail_in + c * hm : nullptr;
-    float *tout = STEREO ? mix_tail_out + c * hm : nullptr;
-    // D-1 samples past the window are visited too: when the block ends exactly on a tile boundary nobody's window reaches
-    // the block's last D-1 samples, and they belong to the tail this call leaves behind
-    constexpr int NJ = (WL + D - 1 + NT - 1) / NT;
-    float vm[NJ], va[NJ], vb[NJ];
+    const long k = k_lo + ((blockIdx.x % wgs_per_channel) * 256 + threadIdx.x) * 4;
+    if (k >= k_hi) return;
+    f4 *p = reinterpret_cast<f4 *>(trig + c * ypitch + k);
+    const f4 v = *p;
+    float a[4], o[4];
 #pragma unroll
-    for (int q = 0; q < NJ; q++) {
-        const int j = t + q * NT;
-        const long g = g0 + j;
-        const bool valid = j < WL + D - 1 && g < n_if;
-        vm[q] = 0.0f;
-        va[q] = 0.0f;
-        vb[q] = 0.0f;
-        if (valid) {
-            vm[q] = dm[g - delay];                             // history in front of the row: negative indices are valid
-            if (STEREO) {
-                va[q] = g >= 0 ? bp[g] : tin[hm + g];
-                if (g > 0) vb[q] = tr[g - 1];                  // PLL[g] = cosf(trigArg[g-1]*ncoScale + phaseAdjust); PLL[0] = state[4]
-            }
+    for (int i = 0; i < 4; i++) a[i] = v[i] * nco_scale + phase_adjust;
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 4; i++) ok = ok && glibc235::sincosf_large_ok(a[i]);
+    if (!__any(!ok)) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float sn;
+            glibc235::sincosf_large_flat(a[i], w24, &sn, &o[i]);
         }
-    }
-    const float first = STEREO ? nco0[c] : 0.0f;
+    } else {
 #pragma unroll
-    for (int q = 0; q < NJ; q++) {
-        const int j = t + q * NT;
-        const long g = g0 + j;
-        if (j >= WL + D - 1) continue;
-        float m = 0.0f, x = 0.0f;
-        if (g < n_if) {
-            m = vm[q];
-            if (STEREO) {
-                if (g >= 0) {
-                    float nco;
-                    if (EXACT) {
-                        const float a = vb[q] * nco_scale + phase_adjust;
-                        nco = g > 0 ? glibc235::cosf_glibc(a) : first;
-                    } else {
-                        const float a = vb[q] * nco_scale + phase_adjust;
-                        const double rev = static_cast<double>(a) * 0.15915494309189533577;
-                        nco = g > 0 ? __builtin_amdgcn_cosf(static_cast<float>(rev - rint(rev))) : first;
+        for (int i = 0; i < 4; i++) o[i] = glibc235::cosf_glibc(a[i]);
+    }
+    if (k + 4 <= k_hi) {
+        *p = (f4){o[0], o[1], o[2], o[3]};
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (k + i < k_hi) trig[c * ypitch + k + i] = o[i];
+    }
+}
+
+// ---- everything behind the PLL ------------------------------------------------------------------------------------
+// The mixer (src/project.cpp:246-248), the two audio convolveBlockFastFIR calls of RF_STEREO -- mono branch on the
+// all-passed discriminator output (:194, :219), stereo branch on the mixer output (:257) --, the L/R combine (:277-280)
+// and the interleaved PCM writer (:292-302), in the reference's evaluation order.  A single-wave workgroup stages the
+// window of its 64*R audio outputs as (mono, mixer) pairs in LDS -- the mixer products are formed while staging and never
+// go to HBM; the two FIRs share the taps, so they ride in the two halves of the packed instructions.  The FIR is the
+// front end's scheme once more: a thread owns R = 8 ADJACENT outputs and visits its window newest sample first, one
+// ds_read_b64 per sample feeds every output the sample belongs to (136 LDS reads per 808 tap-output pairs: the
+// one-read-per-tap form is bound by LDS bandwidth at twice the time), the taps of two steps are one scalar load.
+// Neighbouring lanes' windows start R*D pairs apart; the LDS index j + j / (R*D) makes that an odd number of
+// pairs (41 / 49): conflict-free ds_read_b64.  Mono banks (STEREO = false) run the same kernel on the mono half alone.
+template <int T, int D>
+struct OutX {
+    static constexpr int R = kR;
+    static constexpr int W = D * (R - 1) + T;                   // window samples (= steps) per thread
+    static constexpr int NG = (W + 1) / 2;                      // scalar-load groups: two steps each
+    static constexpr int NOUT = 64 * R;                         // audio outputs per workgroup
+    static constexpr int WL = D * (NOUT - 1) + T;               // window samples per workgroup
+    static constexpr int SEG = R * D;                           // window samples between neighbouring lanes
+    static constexpr int LDSN = WL + WL / SEG + 2;              // pairs in LDS
+    __host__ __device__ static constexpr int idx(int j) { return j + j / SEG; }
+};
+
+template <int T, int D, bool STEREO, int G>
+__device__ __forceinline__ void outx_step(const f2 *__restrict__ wl, const float *__restrict__ table, f2 (&acc)[kR], f16v &hA, f16v &hB)
+{
+    using C = OutX<T, D>;
+    if constexpr (G < C::NG) {
+        float hq[16];
+        if constexpr (G % 2 == 0) {
+            CHS_TAPS_WAIT(hA);
+            if constexpr (G + 1 < C::NG) CHS_TAPS_ISSUE(hB, table, (G + 1) * 64);
+#pragma unroll
+            for (int k = 0; k < 16; k++) hq[k] = hA[k];
+        } else {
+            CHS_TAPS_WAIT(hB);
+            if constexpr (G + 1 < C::NG) CHS_TAPS_ISSUE(hA, table, (G + 1) * 64);
+#pragma unroll
+            for (int k = 0; k < 16; k++) hq[k] = hB[k];
+        }
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int u = 2 * G + e;
+            if (u < C::W) {
+                const int jj = C::W - 1 - u;                    // window sample of this thread, newest first
+                const f2 w = wl[C::idx(jj)];                    // lane base + compile-time offset
+#pragma unroll
+                for (int r = 0; r < kR; r++) {
+                    const int n = r * D + (T - 1) - jj;
+                    if (n >= 0 && n < T) {
+                        const float h = hq[8 * e + r];
+                        if constexpr (STEREO) {
+                            const f2 prod = w * (f2){h, h};
+                            acc[r] = acc[r] + prod;
+                        } else {
+                            const float prod = w.x * h;
+                            acc[r].x = acc[r].x + prod;
+                        }
                     }
-                    x = (va[q] * nco) * 2.0f;                  // the reference's order: (stereo_filt * PLL) * 2
-                    if (g >= n_if - hm) tout[g - (n_if - hm)] = x;
-                } else {
-                    x = va[q];
                 }
             }
         }
-        if (j < WL) win[j] = (f2){m, x};
+#pragma unroll
+        for (int r = 0; r < kR; r++) asm volatile("" : "+v"(acc[r]));
+        outx_step<T, D, STEREO, G + 1>(wl, table, acc, hA, hB);
+    }
+}
+
+template <int T, int D, bool STEREO>
+__global__ __launch_bounds__(64) void chs_out_exact_kernel(const float *__restrict__ demod, long dpitch, int Hd, const float *__restrict__ bpf,
+                                                            const float *__restrict__ nco, long ypitch, const float *__restrict__ nco0,
+                                                            const float *__restrict__ mix_tail_in, float *__restrict__ mix_tail_out, int hm,
+                                                            long n_if, long g_hi, int delay, const float *__restrict__ table,
+                                                            long wgs_per_channel, float *__restrict__ audio, int16_t *__restrict__ pcm,
+                                                            int wrap, long a_lo, long a_hi, long n_out)
+{
+    using C = OutX<T, D>;
+    constexpr int R = kR;
+    __shared__ f2 win[C::LDSN];
+    const int t = threadIdx.x;
+    const long c = blockIdx.x / wgs_per_channel;
+    // this launch: audio outputs [a_lo, a_hi) of the block's n_out, from the IF samples [.., g_hi) that exist by now (a block is
+    // walked in chunks so that the PLL's lanes of one chunk run next to the wide kernels of the next: stereo_bank_process_dev)
+    const long a0 = a_lo + (blockIdx.x % wgs_per_channel) * C::NOUT;
+    const long g0 = D * a0 - (T - 1);                      // IF index of window sample 0
+    const float *dm = demod + c * dpitch + Hd;
+    const float *bp = STEREO ? bpf + c * ypitch : nullptr, *nc = STEREO ? nco + c * ypitch : nullptr;
+    const float *tin = STEREO ? mix_tail_in + c * hm : nullptr;
+    float *tout = STEREO ? mix_tail_out + c * hm : nullptr;
+    const float first = STEREO ? nco0[c] : 0.0f;
+    // D-1 samples past the window are visited too: when the block ends exactly on a tile boundary nobody's window reaches
+    // the block's last D-1 samples, and they belong to the tail this call leaves behind
+    constexpr int NJ = (C::WL + D - 1 + 63) / 64, B = 7;
+    for (int q0 = 0; q0 < NJ; q0 += B) {
+        float vm[B], va[B], vb[B];
+#pragma unroll
+        for (int q = 0; q < B; q++) {                          // a batch's loads in flight before the first use
+            const int j = t + (q0 + q) * 64;
+            const long g = g0 + j;
+            vm[q] = 0.0f;
+            va[q] = 0.0f;
+            vb[q] = first;                                     // PLL[0] = the incoming state's lastOut
+            if (j < C::WL + D - 1 && g < g_hi) {
+                vm[q] = dm[g - delay];                         // history in front of the row: negative indices are valid
+                if (STEREO) {
+                    va[q] = g >= 0 ? bp[g] : tin[hm + g];
+                    if (g > 0) vb[q] = nc[g - 1];              // PLL[g], finished by chs_nco_exact_kernel
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < B; q++) {
+            const int j = t + (q0 + q) * 64;
+            const long g = g0 + j;
+            if (j >= C::WL + D - 1) continue;
+            float m = 0.0f, x = 0.0f;
+            if (g < g_hi) {
+                m = vm[q];
+                if (STEREO) {
+                    if (g >= 0) {
+                        x = (va[q] * vb[q]) * 2.0f;            // the reference's order: (stereo_filt * PLL) * 2
+                        if (g >= n_if - hm) tout[g - (n_if - hm)] = x;
+                    } else {
+                        x = va[q];
+                    }
+                }
+            }
+            if (j < C::WL) win[C::idx(j)] = (f2){m, x};
+        }
     }
     __syncthreads();
     f2 acc[R];
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = (f2){0.0f, 0.0f};
-    const f2 *w0 = win + D * t + (T - 1);
-#pragma unroll 8
-    for (int n = 0; n < T; n++) {
-        const float hn = h[n];                             // wave-uniform: scalar load
+    f16v hA, hB;
+    CHS_TAPS_ISSUE(hA, table, 0);
+    outx_step<T, D, STEREO, 0>(win + (C::SEG + 1) * t, table, acc, hA, hB);
+    const long k0 = a0 + static_cast<long>(t) * R;
+    if (k0 >= a_hi) return;
+    if constexpr (STEREO) {
+        float l[R], rr[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            if (EXACT) {
-                const f2 prod = w0[D * NT * r - n] * (f2){hn, hn};
-                acc[r] = acc[r] + prod;
-            } else {
-                acc[r] = __builtin_elementwise_fma(w0[D * NT * r - n], (f2){hn, hn}, acc[r]);
-            }
+            l[r] = acc[r].y + acc[r].x;                        // src/project.cpp:278-279: left = stereo + mono, right = mono - stereo
+            rr[r] = acc[r].x - acc[r].y;
         }
-    }
+        if (k0 + R <= a_hi) {
+            if (audio) {
+                f4 *pl = reinterpret_cast<f4 *>(audio + c * 2 * n_out + k0), *pr = reinterpret_cast<f4 *>(audio + c * 2 * n_out + n_out + k0);
+                pl[0] = (f4){l[0], l[1], l[2], l[3]};
+                pl[1] = (f4){l[4], l[5], l[6], l[7]};
+                pr[0] = (f4){rr[0], rr[1], rr[2], rr[3]};
+                pr[1] = (f4){rr[4], rr[5], rr[6], rr[7]};
+            }
+            if (pcm) {
+                using s8v = short __attribute__((ext_vector_type(8)));
+                s8v *pp = reinterpret_cast<s8v *>(pcm + 2 * (c * n_out + k0));
+                pp[0] = (s8v){pcm_pack_flat(l[0], wrap), pcm_pack_flat(rr[0], wrap), pcm_pack_flat(l[1], wrap), pcm_pack_flat(rr[1], wrap),
+                              pcm_pack_flat(l[2], wrap), pcm_pack_flat(rr[2], wrap), pcm_pack_flat(l[3], wrap), pcm_pack_flat(rr[3], wrap)};
+                pp[1] = (s8v){pcm_pack_flat(l[4], wrap), pcm_pack_flat(rr[4], wrap), pcm_pack_flat(l[5], wrap), pcm_pack_flat(rr[5], wrap),
+                              pcm_pack_flat(l[6], wrap), pcm_pack_flat(rr[6], wrap), pcm_pack_flat(l[7], wrap), pcm_pack_flat(rr[7], wrap)};
+            }
+        } else {
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-        const long k = a0 + static_cast<long>(r) * NT + t;
-        if (k < n_out) {
-            const float mo = acc[r].x, st = acc[r].y;
-            if (STEREO) {
-                const float l = st + mo, rr = mo - st;     // src/project.cpp:278-279
-                if (audio) {
-                    audio[c * 2 * n_out + k] = l;
-                    audio[c * 2 * n_out + n_out + k] = rr;
+            for (int r = 0; r < R; r++)
+                if (k0 + r < a_hi) {
+                    if (audio) {
+                        audio[c * 2 * n_out + k0 + r] = l[r];
+                        audio[c * 2 * n_out + n_out + k0 + r] = rr[r];
+                    }
+                    if (pcm) {
+                        pcm[2 * (c * n_out + k0 + r)] = pcm_pack_flat(l[r], wrap);
+                        pcm[2 * (c * n_out + k0 + r) + 1] = pcm_pack_flat(rr[r], wrap);
+                    }
                 }
-                if (pcm) {
-                    using s2 = short __attribute__((ext_vector_type(2)));
-                    *reinterpret_cast<s2 *>(pcm + 2 * (c * n_out + k)) = (s2){pcm_pack_flat(l, wrap), pcm_pack_flat(rr, wrap)};
-                }
-            } else {
-                if (audio) audio[c * n_out + k] = mo;
-                if (pcm) pcm[c * n_out + k] = pcm_pack_flat(mo, wrap);
-            }
         }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if (k0 + r < a_hi) {
+                if (audio) audio[c * n_out + k0 + r] = acc[r].x;
+                if (pcm) pcm[c * n_out + k0 + r] = pcm_pack_flat(acc[r].x, wrap);
+            }
     }
 }
 
@@ -422,9 +534,31 @@ struct StereoBank {
     int Ha = 0, delay = 0, Hd = 0, Hm = 0, St = 0;
     long dpitch = 0, ypitch = 0;
     DevBuf<uint8_t> slots;
-    DevBuf<float> fe_table, bpf_table, h_audio;
+    DevBuf<float> fe_table, bpf_table, out_table;
     DevBuf<float> demod, carrier, bpf, trig, pll, nco0, mixtail[2];
     int mix_cur = 0;
+    // A stereo call walks the block in chunks on two internal streams: `wide` carries the front end, the band-pass pair and the
+    // output stage of every chunk, `lanes` the PLL -- the PLL's few waves (one per 64 channels, a dependent chain each) leave
+    // the chip almost idle, and chunk c+1's wide kernels fill it meanwhile.  Events: chunk c's band-pass output is ready
+    // (wide -> lanes), its PLL is through (lanes -> wide); fork / join with the caller's stream around the call.
+    static constexpr int kMaxChunks = 8;
+    int max_chunks = kMaxChunks;
+    hipStream_t wide = nullptr, lanes = nullptr;
+    hipEvent_t ev_bpf[kMaxChunks] = {}, ev_pll[kMaxChunks] = {}, ev_fork = nullptr, ev_join = nullptr;
+    ~StereoBank()
+    {
+        for (hipStream_t st : {wide, lanes})
+            if (st) {
+                (void)hipStreamSynchronize(st);
+                (void)hipStreamDestroy(st);
+            }
+        for (auto &e : ev_bpf)
+            if (e) (void)hipEventDestroy(e);
+        for (auto &e : ev_pll)
+            if (e) (void)hipEventDestroy(e);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+    }
 };
 
 namespace {
@@ -472,40 +606,66 @@ int bpf_table_init(StereoBank &b, const float *h_st, const float *h_car)
 #define CHS_BPF_CASES(X) X(101) X(151) X(13)
 #define CHS_OUT_CASES(X) X(101, 5) X(101, 6) X(13, 5) X(13, 6)
 
+// IF outputs [k_lo, k_hi) of every channel's block
 template <int T, int D>
-int launch_fe(const StereoBank &b, hipStream_t s)
+int launch_fe(const StereoBank &b, long k_lo, long k_hi, hipStream_t s)
 {
     using C = FeX<T, D>;
-    const long ntiles = (b.n_if + C::TILE - 1) / C::TILE;
-    const long wgs = (ntiles + 3) / 4;
-    hipLaunchKernelGGL((chs_fe_exact_kernel<T, D>), dim3(static_cast<unsigned>(wgs * b.n_channels)), dim3(256), 0, s, b.slots.p,
-                       static_cast<long>(b.slot_bytes), static_cast<int>(b.hist_bytes), b.n_if, ntiles, wgs, b.fe_table.p, b.demod.p,
+    const long ntiles = (k_hi - k_lo + C::TILE - 1) / C::TILE;
+    const long wgs = ntiles;
+    hipLaunchKernelGGL((chs_fe_exact_kernel<T, D>), dim3(static_cast<unsigned>(wgs * b.n_channels)), dim3(64), 0, s, b.slots.p,
+                       static_cast<long>(b.slot_bytes), static_cast<int>(b.hist_bytes), k_lo, k_hi, ntiles, wgs, b.fe_table.p, b.demod.p,
                        b.dpitch, b.Hd);
     CHS_LAUNCH_CHECK("chs_fe_exact_kernel");
     return FMRX_OK;
 }
 
 template <int T>
-int launch_bpf(const StereoBank &b, hipStream_t s)
+int launch_bpf(const StereoBank &b, long k_lo, long k_hi, hipStream_t s)
 {
-    const long wgs = (b.n_if + 256 * kR - 1) / (256 * kR);
-    hipLaunchKernelGGL((chs_bpf_exact_kernel<T>), dim3(static_cast<unsigned>(wgs * b.n_channels)), dim3(256), 0, s, b.demod.p, b.dpitch,
-                       b.Hd, b.n_if, wgs, b.bpf_table.p, b.bpf.p, b.carrier.p, b.ypitch);
+    const long wgs = (k_hi - k_lo + 64 * kR - 1) / (64 * kR);
+    hipLaunchKernelGGL((chs_bpf_exact_kernel<T>), dim3(static_cast<unsigned>(wgs * b.n_channels)), dim3(64), 0, s, b.demod.p, b.dpitch,
+                       b.Hd, k_lo, k_hi, wgs, b.bpf_table.p, b.bpf.p, b.carrier.p, b.ypitch);
     CHS_LAUNCH_CHECK("chs_bpf_exact_kernel");
     return FMRX_OK;
 }
 
+// audio outputs [a_lo, a_hi) of every channel's block, from the IF samples [.., g_hi)
 template <int T, int D, bool STEREO>
-int launch_out(StereoBank &b, float *d_audio, int16_t *d_pcm, int wrap, hipStream_t s)
+int launch_out(StereoBank &b, float *d_audio, int16_t *d_pcm, int wrap, long a_lo, long a_hi, long g_hi, hipStream_t s)
 {
-    constexpr int R = 2, NT = 256;
-    constexpr size_t lds = (static_cast<size_t>(D) * (NT * R - 1) + T) * sizeof(f2);
-    const long wgs = (b.n_audio + NT * R - 1) / (NT * R);
-    hipLaunchKernelGGL((chs_out_kernel<T, D, R, NT, true, STEREO>), dim3(static_cast<unsigned>(wgs * b.n_channels)), dim3(NT), lds, s,
-                       b.demod.p, b.dpitch, b.Hd, b.bpf.p, b.trig.p, b.ypitch, b.nco0.p, b.mixtail[b.mix_cur].p,
-                       b.mixtail[b.mix_cur ^ 1].p, b.Hm, b.n_if, b.delay, 2.0f, 0.0f, b.h_audio.p, wgs, d_audio, d_pcm, wrap,
-                       b.n_audio);
-    CHS_LAUNCH_CHECK("chs_out_kernel");
+    using C = OutX<T, D>;
+    if ((reinterpret_cast<uintptr_t>(d_audio) % 16) || (reinterpret_cast<uintptr_t>(d_pcm) % 16) || (STEREO && b.n_audio % 4))
+        return fail(FMRX_EINVAL, "channels: output buffers must be 16-byte aligned");
+    const long wgs = (a_hi - a_lo + C::NOUT - 1) / C::NOUT;
+    hipLaunchKernelGGL((chs_out_exact_kernel<T, D, STEREO>), dim3(static_cast<unsigned>(wgs * b.n_channels)), dim3(64), 0, s, b.demod.p,
+                       b.dpitch, b.Hd, b.bpf.p, b.trig.p, b.ypitch, b.nco0.p, b.mixtail[b.mix_cur].p, b.mixtail[b.mix_cur ^ 1].p, b.Hm,
+                       b.n_if, g_hi, b.delay, b.out_table.p, wgs, d_audio, d_pcm, wrap, a_lo, a_hi, b.n_audio);
+    CHS_LAUNCH_CHECK("chs_out_exact_kernel");
+    return FMRX_OK;
+}
+
+int launch_nco(const StereoBank &b, long k_lo, long k_hi, hipStream_t s)
+{
+    const long wgs = (k_hi - k_lo + 1023) / 1024;
+    hipLaunchKernelGGL(chs_nco_exact_kernel, dim3(static_cast<unsigned>(wgs * b.n_channels)), dim3(256), 0, s, b.trig.p, b.ypitch, k_lo, k_hi, wgs,
+                       2.0f, 0.0f);
+    CHS_LAUNCH_CHECK("chs_nco_exact_kernel");
+    return FMRX_OK;
+}
+
+template <int T, int D>
+int out_table_init(StereoBank &b, const float *h)
+{
+    using C = OutX<T, D>;
+    std::vector<float> tab(static_cast<size_t>(C::NG) * 16, 0.0f);
+    for (int u = 0; u < C::W; u++)
+        for (int r = 0; r < kR; r++) {
+            const int n = r * D + (T - 1) - (C::W - 1 - u);
+            if (n >= 0 && n < T) tab[static_cast<size_t>(u) * 8 + r] = h[n];
+        }
+    FMRX_TRY(b.out_table.alloc(tab.size()));
+    FMRX_HIP(hipMemcpy(b.out_table.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
     return FMRX_OK;
 }
 
@@ -546,8 +706,9 @@ int stereo_bank_create(StereoBank **out, const fmrx_params &p, int n_channels, i
 #undef X
         std::vector<float> ha(p.audio_taps);
         design_lpf(static_cast<float>(p.if_Fs), 16000.0f, p.audio_taps, ha.data());           // src/project.cpp:321
-        FMRX_TRY(b->h_audio.alloc(p.audio_taps));
-        FMRX_HIP(hipMemcpy(b->h_audio.p, ha.data(), p.audio_taps * sizeof(float), hipMemcpyHostToDevice));
+#define X(T_, D_) if (p.audio_taps == T_ && p.audio_decim == D_) FMRX_TRY((out_table_init<T_, D_>(*b, ha.data())));
+        CHS_OUT_CASES(X)
+#undef X
         b->n = static_cast<long>(block_bytes / 2);
         b->n_if = b->n / p.rf_decim;
         b->n_audio = b->n_if / p.audio_decim;
@@ -590,6 +751,12 @@ int stereo_bank_create(StereoBank **out, const fmrx_params &p, int n_channels, i
             hipLaunchKernelGGL(chs_fill_state_kernel, dim3(static_cast<unsigned>((8 * N + 255) / 256)), dim3(256), 0, nullptr, b->pll.p,
                                static_cast<long>(8 * N));
             CHS_LAUNCH_CHECK("chs_fill_state_kernel");
+            FMRX_HIP(hipStreamCreateWithFlags(&b->wide, hipStreamNonBlocking));
+            FMRX_HIP(hipStreamCreateWithFlags(&b->lanes, hipStreamNonBlocking));
+            for (auto &e : b->ev_bpf) FMRX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            for (auto &e : b->ev_pll) FMRX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            FMRX_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+            FMRX_HIP(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
         }
         FMRX_HIP(hipDeviceSynchronize());
         return FMRX_OK;
@@ -638,22 +805,67 @@ int stereo_bank_reset(StereoBank *b, int channel)
 int stereo_bank_process_dev(StereoBank *b, float *d_audio, int16_t *d_pcm, int wrap, hipStream_t s)
 {
     const fmrx_params &p = b->p;
-#define X(T_, D_) if (p.rf_taps == T_ && p.rf_decim == D_) FMRX_TRY((launch_fe<T_, D_>(*b, s)));
-    CHS_FE_CASES(X)
+    auto fe = [&](long k_lo, long k_hi, hipStream_t st) -> int {
+#define X(T_, D_) if (p.rf_taps == T_ && p.rf_decim == D_) return launch_fe<T_, D_>(*b, k_lo, k_hi, st);
+        CHS_FE_CASES(X)
 #undef X
+        return FMRX_EINVAL;
+    };
     if (b->audio_channels == 2) {
-#define X(T_) if (p.stereo_taps == T_) FMRX_TRY(launch_bpf<T_>(*b, s));
-        CHS_BPF_CASES(X)
+        auto bpf = [&](long k_lo, long k_hi, hipStream_t st) -> int {
+#define X(T_) if (p.stereo_taps == T_) return launch_bpf<T_>(*b, k_lo, k_hi, st);
+            CHS_BPF_CASES(X)
 #undef X
-        // fmPLL(carrier_filt, 19 kHz, if_Fs, ncoScale 2, phaseAdjust 0, normBandwidth 0.01): src/project.cpp:237
-        FMRX_TRY(k_fm_pll_channels(b->carrier.p, b->ypitch, static_cast<size_t>(b->n_if), b->n_channels, b->trig.p, b->ypitch, b->pll.p,
-                                   b->nco0.p, 19e3f, static_cast<float>(p.if_Fs), 2.0f, 0.0f, 0.01f, s));
-#define X(T_, D_) if (p.audio_taps == T_ && p.audio_decim == D_) FMRX_TRY((launch_out<T_, D_, true>(*b, d_audio, d_pcm, wrap, s)));
-        CHS_OUT_CASES(X)
+            return FMRX_EINVAL;
+        };
+        auto out = [&](long a_lo, long a_hi, long g_hi, hipStream_t st) -> int {
+#define X(T_, D_) if (p.audio_taps == T_ && p.audio_decim == D_) return launch_out<T_, D_, true>(*b, d_audio, d_pcm, wrap, a_lo, a_hi, g_hi, st);
+            CHS_OUT_CASES(X)
 #undef X
+            return FMRX_EINVAL;
+        };
+        // chunks of whole output workgroups (512 audio samples); chunk c = audio [a_c, a_c+1) = IF [a_c * D, a_c+1 * D)
+        const long unit = 512;
+        long per = (b->n_audio + b->max_chunks - 1) / b->max_chunks;
+        per = (per + unit - 1) / unit * unit;
+        const int K = static_cast<int>((b->n_audio + per - 1) / per);
+        hipStream_t sw = K > 1 ? b->wide : s, sl = K > 1 ? b->lanes : s;
+        if (K > 1) {   // whatever the caller's stream did before the call (loading the slots, reading the last output) comes first
+            FMRX_HIP(hipEventRecord(b->ev_fork, s));
+            FMRX_HIP(hipStreamWaitEvent(sw, b->ev_fork, 0));
+            FMRX_HIP(hipStreamWaitEvent(sl, b->ev_fork, 0));
+        }
+        for (int c = 0; c <= K; c++) {
+            if (c < K) {
+                const long a_lo = c * per, a_hi = a_lo + per < b->n_audio ? a_lo + per : b->n_audio;
+                const long k_lo = a_lo * p.audio_decim, k_hi = a_hi * p.audio_decim;
+                FMRX_TRY(fe(k_lo, k_hi, sw));
+                FMRX_TRY(bpf(k_lo, k_hi, sw));
+                if (K > 1) {
+                    FMRX_HIP(hipEventRecord(b->ev_bpf[c], sw));
+                    FMRX_HIP(hipStreamWaitEvent(sl, b->ev_bpf[c], 0));
+                }
+                // fmPLL(carrier_filt, 19 kHz, if_Fs, ncoScale 2, phaseAdjust 0, normBandwidth 0.01): src/project.cpp:237
+                FMRX_TRY(k_fm_pll_channels(b->carrier.p + k_lo, b->ypitch, static_cast<size_t>(k_hi - k_lo), b->n_channels, b->trig.p + k_lo,
+                                           b->ypitch, b->pll.p, c == 0 ? b->nco0.p : nullptr, 19e3f, static_cast<float>(p.if_Fs), 2.0f, 0.0f,
+                                           0.01f, sl));
+                if (K > 1) FMRX_HIP(hipEventRecord(b->ev_pll[c], sl));
+            }
+            if (c > 0) {   // the output stage of the chunk before, behind this chunk's front end and band-pass pair on the wide stream
+                const long a_lo = (c - 1) * per, a_hi = a_lo + per < b->n_audio ? a_lo + per : b->n_audio;
+                if (K > 1) FMRX_HIP(hipStreamWaitEvent(sw, b->ev_pll[c - 1], 0));
+                FMRX_TRY(launch_nco(*b, a_lo * p.audio_decim, a_hi * p.audio_decim, sw));
+                FMRX_TRY(out(a_lo, a_hi, a_hi * p.audio_decim, sw));
+            }
+        }
+        if (K > 1) {
+            FMRX_HIP(hipEventRecord(b->ev_join, sw));
+            FMRX_HIP(hipStreamWaitEvent(s, b->ev_join, 0));
+        }
         b->mix_cur ^= 1;
     } else {
-#define X(T_, D_) if (p.audio_taps == T_ && p.audio_decim == D_) FMRX_TRY((launch_out<T_, D_, false>(*b, d_audio, d_pcm, wrap, s)));
+        FMRX_TRY(fe(0, b->n_if, s));
+#define X(T_, D_) if (p.audio_taps == T_ && p.audio_decim == D_) FMRX_TRY((launch_out<T_, D_, false>(*b, d_audio, d_pcm, wrap, 0, b->n_audio, b->n_if, s)));
         CHS_OUT_CASES(X)
 #undef X
     }
@@ -684,10 +896,8 @@ int stereo_bank_read_tap(StereoBank *b, int channel, int which, float *out, size
     *n = cnt;
     if (!out) return FMRX_OK;
     if (which == FMRX_TAP_PLL) {
-        std::vector<float> t(n_if);
-        FMRX_HIP(hipMemcpy(t.data(), src, n_if * sizeof(float), hipMemcpyDeviceToHost));
         FMRX_HIP(hipMemcpy(out, b->nco0.p + channel, sizeof(float), hipMemcpyDeviceToHost));
-        for (size_t k = 0; k < n_if; k++) out[k + 1] = glibc235::cosf_glibc(t[k] * 2.0f + 0.0f);   // same function, host build
+        FMRX_HIP(hipMemcpy(out + 1, src, n_if * sizeof(float), hipMemcpyDeviceToHost));
         return FMRX_OK;
     }
     FMRX_HIP(hipMemcpy(out, src, cnt * sizeof(float), hipMemcpyDeviceToHost));

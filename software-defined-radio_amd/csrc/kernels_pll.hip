@@ -709,7 +709,7 @@ __global__ __launch_bounds__(64) void pll_channels_kernel(const float *__restric
     float *st = state + 8 * ch;
     PllState s{st[0], st[1], st[2], st[3], st[4], st[5], 0.0f};
     if (MATH == kFast) s.fr = atan2f(st[3], st[2]) * 0.15915494309189533577f;
-    nco0[ch] = s.last;
+    if (nco0) nco0[ch] = s.last;
     const f4 *in4 = reinterpret_cast<const f4 *>(in + ch * pitch_in);
     f4 *out4 = reinterpret_cast<f4 *>(trig + ch * pitch_trig);
     const long ng = n / 4;
