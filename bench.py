@@ -109,8 +109,30 @@ def cpu_baseline(seconds: float = 10.0) -> dict:
         ta.start(); tb.start(); ta.join(); tb.join()
         return done[0], time.perf_counter() - t0
 
+    def run_mode(mode: int, channels: int, budget_s: float) -> dict:
+        """single thread, another mode / the stereo chain: the figure that stands beside that mode's GPU leg"""
+        p = o.mode_params(mode, 101, 101, 101)
+        nb = 20
+        data = synth.synth_fm_u8(p.block_bytes // 2 * nb, float(p.rf_Fs), seed=0x3D74 + 10 + mode)
+        pl = o.pipeline(mode, channels)
+        t0 = time.perf_counter()
+        done = 0
+        while True:
+            for b in range(nb):
+                pl.process(data[b * p.block_bytes:(b + 1) * p.block_bytes])
+            done += p.block_bytes // 2 * nb
+            if time.perf_counter() - t0 >= budget_s:
+                break
+        dt = time.perf_counter() - t0
+        return {"value": round(done / dt / 1e6, 2), "unit": "MS/s", "cores": 1, "kind": "port",
+                "sample": f"mode {mode} {'stereo' if channels == 2 else 'mono'} chain (101/101/101 taps), {done} complex samples in {dt:.1f} s, "
+                          "single thread, reference-size blocks"}
+
     n1, t1 = run(seconds)
     n2, t2 = run_two_threads(seconds * 0.3)
+    per_mode = {"mode1_mono": run_mode(1, 1, seconds * 0.3), "mode2_mono": run_mode(2, 1, seconds * 0.3),
+                "mode3_mono": run_mode(3, 1, seconds * 0.3), "mode0_stereo": run_mode(0, 2, seconds * 0.3),
+                "mode1_stereo": run_mode(1, 2, seconds * 0.2)}
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(cores, 64))
     with ThreadPoolExecutor(cores) as ex:                # ctypes releases the GIL inside the C call
@@ -126,6 +148,7 @@ def cpu_baseline(seconds: float = 10.0) -> dict:
                                           "stage calls through ctypes/numpy, so an upper bound on the reference binary's overhead"},
         "all_cores": {"value": round(sum(r[0] for r in res) / wall / 1e6, 2), "unit": "MS/s", "cores": cores,
                       "sample": f"{cores} independent channels, one per core, {wall:.1f} s"},
+        "legs": per_mode,
     }
 
 
@@ -276,6 +299,22 @@ def side_legs(torch, fmrx, synth, args, pl, step, d_iq, n_bytes, stream) -> dict
         "frac": round(S2_BYTES * n_samples / (fe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "steps": k,
         "note": "avg_launch_ms = step time minus the audio kernel's event-bracketed time"}
     pl.set_option("fe_variant", "mfma")
+    # (1b) the headline step at 8x the Infinity Cache: 1024 blocks = 2.1 GB of input resident per step (the default 524 MB is only 2x the
+    #      256 MiB last-level cache; a cyclic sweep should not profit from it, and this leg shows whether it does)
+    try:
+        big = d_iq.repeat(1024 * BLOCK_SAMPLES * 2 // n_bytes) if (1024 * BLOCK_SAMPLES * 2) % n_bytes == 0 else None
+        if big is not None:
+            q = fmrx.Pipeline(0, 1, rf_taps=101, base_audio_taps=101, max_block_bytes=big.numel(), device=torch.cuda.current_device())
+            d_pcm_big = torch.empty(q.n_audio(big.numel()), dtype=torch.int16, device="cuda")
+            ms = event_ms(torch, lambda: q.process_dev(big.data_ptr(), big.numel(), None, d_pcm_big.data_ptr(), wrap=True, stream=stream), 10, warm=5)
+            name, d = leg("mono_1024_blocks", "the headline step with 1024 x 1,024,000-sample blocks (2.1 GB of u8 I/Q, 8 x the 256 MiB Infinity Cache) "
+                          "resident per step: mono_fused_kernel<101,10,101,5>, s16 out", big.numel() // 2, ms, S3_BYTES)
+            legs[name] = d
+            q.close()
+            del q, big, d_pcm_big
+            torch.cuda.empty_cache()
+    except Exception as e:
+        legs["mono_1024_blocks"] = {"error": str(e)}
     # (2) S2: matrix-core front end + discriminator to HBM, then the audio kernel (the two-kernel path)
     pl.set_option("fused_min_audio", 10**12)
     ms = event_ms(torch, step, k)
@@ -322,9 +361,13 @@ def side_legs(torch, fmrx, synth, args, pl, step, d_iq, n_bytes, stream) -> dict
         nm, d = leg(name, what, nb // 2, ms, bytes_per_sample)
         if channels == 2:
             d["pll_repaired_segments"] = q.pll_diagnostics()[0]
+            d["tolerance"] = TOL_FAST
         legs[nm] = d
         q.close()
 
+    TOL_FAST = ("audio RMS error vs the reference <= 1e-4 for the first 0.13 s of a stream, <= 0.06 ulp(trigArg(t)) after (2.2e-4 at 1 s, "
+                "5.5e-4 at 2.1 s: the reference's own float32 phase grid, DESIGN.md section 2); mono sum (L+R)/2 <= 2e-6 throughout")
+    TOL_EXACT = "bit-exact: left / right equal the compiled reference's for any stream length (SHA-256 over 2.13 s, tests/golden/stereo_long_mode0.npz)"
     mode_leg("mode1_mono", 1, 1, 256, "mode 1 mono (1.44 MS/s, decim 5 x 6), fused kernel, 256 blocks of 614,400 samples", 2.0 + 2.0 / 30.0, 1228800)
     mode_leg("mode2_mono", 2, 1, 63, "mode 2 mono (U/D = 147/800 resampler), 63 blocks of 1,008,000 samples", 2.0 + 2.0 * 147 / 8000.0, 2016000)
     mode_leg("mode3_mono", 3, 1, 63, "mode 3 mono (960 kS/s, U/D = 441/3200), 63 blocks of 1,008,000 samples", 2.0 + 2.0 * 441 / 9600.0, 2016000)
@@ -339,6 +382,58 @@ def side_legs(torch, fmrx, synth, args, pl, step, d_iq, n_bytes, stream) -> dict
              "software-pipelined over two streams), stream continued", 2.0 + 4.0 / 50.0, 2048000, base_blocks=3, options={"overlap_calls": 1})
     mode_leg("mode0_stereo_18_blocks_overlapped", 0, 2, 18, "mode 0 stereo, 18 x 1,024,000-sample blocks per step, option overlap_calls = 1, stream continued",
              2.0 + 4.0 / 50.0, 2048000, base_blocks=3, options={"overlap_calls": 1})
+    # (4b) the CONFORMING stereo paths (within the north star's 1e-4 for any stream length = bit-exact):
+    #      single stream: the bit-exact mode (every stage in the reference's order, fmPLL walked by one lane)
+    try:
+        nb = 2048000
+        p = fmrx.modeParams(0)
+        iq = synth.synth_fm_u8(nb // 2, float(p.rf_Fs), seed=0x3D74 + 10)
+        d_in = torch.from_numpy(iq).cuda()
+        q = fmrx.Pipeline(0, 2, max_block_bytes=nb, device=torch.cuda.current_device())
+        q.set_force_generic(True)
+        d_pcm = torch.empty(2 * q.n_audio(nb), dtype=torch.int16, device="cuda")
+        ms = event_ms(torch, lambda: q.process_dev(d_in.data_ptr(), nb, None, d_pcm.data_ptr(), wrap=True, stream=stream), 2, warm=1)
+        nm, d = leg("mode0_stereo_exact", "mode 0 stereo, ONE stream, bit-exact mode (set_force_generic / CLI --exact): reference evaluation order "
+                    "everywhere, fmPLL's recurrence walked by one lane; one 1,024,000-sample block per step", nb // 2, ms, 2.0 + 4.0 / 50.0)
+        d["tolerance"] = TOL_EXACT
+        d["x_real_time"] = round(nb / 2 / 2.4e6 / (ms * 1e-3), 2)
+        legs[nm] = d
+        q.close()
+        del d_in, d_pcm
+    except Exception as e:
+        legs["mode0_stereo_exact"] = {"error": str(e)}
+    #      many streams: the receiver bank, one lane per channel walks the exact recurrence (fmrx_channels_create_ex, exact = 1)
+    def bank_leg(name, mode, nch, blocks_per_call, calls):
+        p = fmrx.modeParams(mode)
+        bb = int(p.block_bytes) * blocks_per_call
+        ns = bb // 2
+        distinct = 64                                          # distinct signals dealt round-robin over the channels: every lane of a wave differs
+        base = torch.stack([torch.from_numpy(synth.synth_fm_u8(ns, float(p.rf_Fs), seed=0x3D74 + c, start=7919 * c)) for c in range(distinct)]).cuda()
+        chs = fmrx.Channels(mode, nch, audio_channels=2, exact=True, block_bytes=bb, device=torch.cuda.current_device())
+        src = base.repeat((nch + distinct - 1) // distinct, 1)[:nch].contiguous()
+        chs.load_dev(src.data_ptr(), stream)
+        del src, base
+        d_pcm_all = torch.empty(nch * chs.n_audio * 2, dtype=torch.int16, device="cuda")
+        ms = event_ms(torch, lambda: chs.process_dev(None, d_pcm_all.data_ptr(), wrap=True, stream=stream), calls, warm=2)
+        nm, d = leg(name, f"{nch} independent mode-{mode} STEREO receivers, {ns:,} samples ({blocks_per_call} reference block(s)) each per call, "
+                    "fmrx_channels_create_ex(exact = 1): reference evaluation order in every stage, fmPLL one lane per channel with glibc's "
+                    "sinf/cosf/atan2f; s16 L,R out; inputs resident in HBM, 64 distinct signals dealt over the channels", nch * ns, ms,
+                    2.0 + 4.0 / (p.rf_decim * p.audio_decim))
+        d["tolerance"] = TOL_EXACT
+        d["channels"] = nch
+        d["channels_at_real_time"] = int(nch * (ns / float(p.rf_Fs)) / (ms * 1e-3))
+        d["bound"] = ("vector ALU, not HBM: the reference's order is 2 separately rounded vector operations per tap and output (nothing for the matrix "
+                      "cores), ~52 lane-instructions per input sample in total; frac is reported on the HBM peak for comparability only")
+        legs[nm] = d
+        chs.close()
+        del chs, d_pcm_all
+        torch.cuda.empty_cache()
+    try:
+        bank_leg("stereo_channels_exact", 0, 16384, 4, 3)
+        bank_leg("stereo_channels_exact_65536", 0, 65536, 1, 3)
+        bank_leg("stereo_channels_exact_mode1", 1, 16384, 4, 3)
+    except Exception as e:
+        legs["stereo_channels_exact_error"] = {"error": str(e)}
     # (5) a live channel's regime: reference-size blocks (51,200 samples), one call per block, device-resident
     q = fmrx.Pipeline(0, 1, device=torch.cuda.current_device())
     d_pcm = torch.empty(1024, dtype=torch.int16, device="cuda")
@@ -475,7 +570,14 @@ def main() -> int:
 
     fmrx = importlib.import_module("software-defined-radio_amd")
     synth = importlib.import_module("software-defined-radio_amd.synth")
-    stray = sorted(k for k in os.environ if k.startswith("FMRX_") and k not in ("FMRX_LIB", "FMRX_NO_TORCH"))
+    stray = sorted(k for k in os.environ if k.startswith("FMRX_") and k != "FMRX_NO_TORCH")
+    # which library is being timed: path, SHA-256 of the file, and the identity it reports itself (hash of its sources)
+    import hashlib
+    lib_version = fmrx.lib.fmrx_version().decode()
+    lib_id = {"path": os.path.relpath(fmrx.LIB_PATH, ROOT) if fmrx.LIB_PATH.startswith(ROOT) else fmrx.LIB_PATH,
+              "sha256": hashlib.sha256(open(fmrx.LIB_PATH, "rb").read()).hexdigest(), "version": lib_version,
+              "FMRX_LIB": os.environ.get("FMRX_LIB")}
+    lib_src = lib_version.split("src:")[-1] if "src:" in lib_version else None
 
     # ---- device-resident synthetic stream: this rank's channel ----
     B = args.blocks
@@ -532,9 +634,13 @@ def main() -> int:
             try:
                 tj = json.load(open(tpath))
                 if int(tj.get("blocks", -1)) == B and tj.get("output") == "s16":
-                    traffic = tj.get("hbm_bytes_per_launch")
-                    traffic_source = ("profiles/fe_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
-                                      f"({tj.get('round', 'earlier round')}); a committed constant, NOT measured in this run")
+                    if tj.get("lib_src") and tj.get("lib_src") == lib_src:
+                        traffic = tj.get("hbm_bytes_per_launch")
+                        traffic_source = ("profiles/fe_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on this "
+                                          f"build (src:{lib_src}, {tj.get('round', 'earlier round')}); a committed constant, NOT measured in this run")
+                    else:
+                        traffic_source = (f"profiles/fe_traffic.json was collected on build src:{tj.get('lib_src')}, this library is src:{lib_src}: "
+                                          "stale, not reported")
             except Exception:
                 traffic = None
         out = {
@@ -548,7 +654,7 @@ def main() -> int:
                             "offline: one long stream per GPU, all blocks of a step in one block-parallel call",
                 "blocks_per_step": B, "samples_per_step_per_gpu": n_samples,
                 "sharding": f"{world} independent channel(s), one per GPU, no collective (control plane: {args.dist_backend})",
-                "settle_ms": args.settle_ms, "fmrx_env": stray,
+                "settle_ms": args.settle_ms, "fmrx_env": stray, "library": lib_id,
             },
             "roofline": {
                 "kernel": ("mono_fused_kernel<101,10,101,5> (u8 I/Q -> 101-tap FIR, decimate 10 (int8 MFMA) -> FM "

@@ -6,6 +6,7 @@
 // become FMRX_EINVAL) -> H2D into per-thread scratch -> HIP kernel(s) -> D2H.
 // No stage has a CPU implementation: without a device they return FMRX_ENODEV.
 #include "fmrx_internal.hpp"
+#include "build_id.hpp"   // FMRX_SRC_HASH: written by the Makefile (SHA-256 over the library's sources)
 
 namespace fmrx {
 
@@ -151,9 +152,9 @@ extern "C" {
 const char *fmrx_version(void)
 {
 #ifdef FMRX_TUNING
-    return "fmrx 0.2 (gfx950, TUNING build: ablation kernels included)";
+    return "fmrx 0.3 (gfx950, TUNING build: ablation kernels included) src:" FMRX_SRC_HASH;
 #else
-    return "fmrx 0.2 (gfx950)";
+    return "fmrx 0.3 (gfx950) src:" FMRX_SRC_HASH;
 #endif
 }
 

@@ -51,3 +51,17 @@ def test_bench_json_contract(fmrx):
     assert out["legs"]["small_block"]["us_per_block"] > 0
     assert out["config"]["fmrx_env"] == []
     assert "two_thread_pipeline" in c
+    # every stereo number carries the bound it meets; the conforming (bit-exact) paths are measured too
+    for k, g in out["legs"].items():
+        if "stereo" in k and "error" not in g:
+            assert "tolerance" in g, k
+    assert out["legs"]["mode0_stereo_exact"]["tolerance"].startswith("bit-exact")
+    bank = out["legs"]["stereo_channels_exact"]
+    assert bank["tolerance"].startswith("bit-exact") and bank["value"] > 1e4 and bank["channels"] >= 256
+    # the CPU figure beside every mode's leg
+    for k in ("mode1_mono", "mode2_mono", "mode3_mono", "mode0_stereo"):
+        assert c["legs"][k]["value"] > 0.5 and c["legs"][k]["cores"] == 1
+    # the line says which library was timed
+    lib = out["config"]["library"]
+    assert len(lib["sha256"]) == 64 and "src:" in lib["version"] and lib["path"].endswith("libfmrx.so")
+    assert out["legs"]["mono_1024_blocks"]["frac"] > 0.3
