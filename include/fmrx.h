@@ -87,6 +87,9 @@ FMRX_API int fmrx_set_device(int device);
  *   "pll_align"        1 = lanes of the parallel PLL (pll_start 0) start on a multiple of the loop's period, 0 (default) = exactly pll_warmup early
  *   "pll_mode"         stereo PLL of the specialised pipeline: 0 = parallel in time, fast math (default),
  *                      1 = serial, fast math, 2 = serial, glibc's functions (cause-by-cause variants)
+ *   "demod"            0 (default) = the C++ reference's discriminator fmDemod (src/filter.cpp:248-266); 1 = the Python model's
+ *                      arctangent demodulator fmDemodArctan (model/fmSupportLib.py:502-531, float64 atan2 + unwrap): the pipeline
+ *                      then runs its unfused kernels (front end -> IF stream -> arctan -> audio / stereo stages)
  *   "fused_tune", "fe_mfma_tune"              ablation kernels (timing only, WRONG results): FMRX_EINVAL unless the
  *                                            library was built with -DFMRX_TUNING (make TUNING=1; never shipped) */
 FMRX_API int fmrx_set_option(const char *name, long value);
@@ -140,6 +143,12 @@ FMRX_API int fmrx_downsample(float *out, size_t *n_out, const float *in, size_t 
 /* replaces fmDemod  include/filter.h:41, src/filter.cpp:248-266.  out[n];
  * *prev_i / *prev_q in/out. */
 FMRX_API int fmrx_fm_demod(float *out, const float *I, const float *Q, size_t n, float *prev_i, float *prev_q);
+/* the arctangent demodulator of the reference's Python MODEL, fmDemodArctan  model/fmSupportLib.py:502-531 (the C++ receiver
+ * uses fmDemod above; BASELINE.json names "arctan/PLL demod"): out[k] = the phase step atan2(Q[k], I[k]) - previous phase,
+ * unwrapped into (-pi, pi] by np.unwrap's rule; float64 like the model.  *prev_phase in/out: the model's running (unwrapped)
+ * phase.  Within 1e-9 of the model (the model's own rounding of its growing phase is 1e-12; tests/golden/arctan.npz).
+ * In a pipeline: option "demod" = 1 (FMRX_DEMOD=arctan) replaces the discriminator by this one. */
+FMRX_API int fmrx_fm_demod_arctan(double *out, const double *I, const double *Q, size_t n, double *prev_phase);
 /* replaces allPass  include/filter.h:18, src/filter.cpp:14-29 (note the
  * reference's argument order: in, state, out).  out[n]; state[nstate] in/out;
  * requires n >= nstate. */

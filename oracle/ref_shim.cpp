@@ -7,7 +7,8 @@
  * oracle/Makefile.  It exists so tests can (1) validate oracle/fm_oracle.c
  * bit-for-bit against the reference and (2) generate tests/golden/ vectors.
  * It exists only in the build container: /root/reference is absent on the GPU
- * box, where the prebuilt oracle/_ref/libfmref.so travels as a binary.
+ * box, and oracle/_ref/ is git-ignored AND gpurun-ignored -- nothing derived from
+ * the reference travels; there the tests run on the oracle and the committed fixtures.
  *
  * The reference's thread bodies (project.cpp RF_FrontEnd/RF_MONO/RF_STEREO)
  * loop forever and exit(1) at EOF, so the block pipelines below replay their

@@ -88,6 +88,8 @@ _sig("fmrx_upsample", [_f32p, _sz, _f32p, _int])
 _sig("fmrx_downsample", [_f32p, C.POINTER(_sz), _f32p, _sz, C.c_ushort])
 _sig("fmrx_fm_demod", [_f32p, _f32p, _f32p, _sz, C.POINTER(_flt), C.POINTER(_flt)])
 _sig("fmrx_all_pass", [_f32p, _sz, _f32p, _sz, _f32p])
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_sig("fmrx_fm_demod_arctan", [_f64p, _f64p, _f64p, _sz, C.POINTER(C.c_double)])
 _sig("fmrx_fm_pll", [_f32p, _sz, _f32p, _f32p, _flt, _flt, _flt, _flt, _flt])
 _sig("fmrx_stereo_mix", [_f32p, _f32p, _sz, _f32p])
 _sig("fmrx_stereo_combine", [_f32p, _f32p, _sz, _f32p, _f32p])
@@ -176,7 +178,7 @@ def set_device(dev: int) -> None:
     _check(lib.fmrx_set_device(dev))
 
 
-_FE_VARIANTS = {"mfma": 0, "valu": 1}
+_FE_VARIANTS = {"mfma": 0, "valu": 1, "discriminator": 0, "arctan": 1}   # option values that have names
 
 
 def set_option(name: str, value) -> None:
@@ -285,6 +287,15 @@ def fmDemod(I, Q, prev_i=0.0, prev_q=0.0):
     pi, pq = _flt(prev_i), _flt(prev_q)
     _check(lib.fmrx_fm_demod(out, I, Q, len(I), C.byref(pi), C.byref(pq)))
     return out, pi.value, pq.value
+
+
+def fmDemodArctan(I, Q, prev_phase=0.0):
+    """model/fmSupportLib.py:502-531 -> (fm_demod, prev_phase): the Python model's arctangent demodulator, float64."""
+    I, Q = np.ascontiguousarray(I, np.float64), np.ascontiguousarray(Q, np.float64)
+    out = np.zeros(len(I), np.float64)
+    ph = C.c_double(prev_phase)
+    _check(lib.fmrx_fm_demod_arctan(out, I, Q, len(I), C.byref(ph)))
+    return out, ph.value
 
 
 def allPass(input_block, state_block):

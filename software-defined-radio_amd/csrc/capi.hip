@@ -59,6 +59,7 @@ bool option_ref(Options &o, const char *name, long **as_long, int **as_int)
     else if (n == "pll_start") *as_int = &o.pll_start;
     else if (n == "pll_align") *as_int = &o.pll_align;
     else if (n == "pll_mode") *as_int = &o.pll_mode;
+    else if (n == "demod") *as_int = &o.demod;
     else if (n == "resample_chains") *as_int = &o.resample_chains;
     else if (n == "overlap_calls") *as_int = &o.overlap_calls;
     else if (n == "fused_tune") *as_int = &o.fused_tune;
@@ -85,6 +86,7 @@ Options &default_options()
         if (const char *e = std::getenv("FMRX_PLL_START")) d.pll_start = std::atoi(e);
         if (const char *e = std::getenv("FMRX_PLL_ALIGN")) d.pll_align = std::atoi(e);
         if (const char *e = std::getenv("FMRX_PLL_MODE")) d.pll_mode = std::atoi(e);
+        if (const char *e = std::getenv("FMRX_DEMOD")) d.demod = std::strcmp(e, "arctan") == 0 ? 1 : std::atoi(e);
 #ifdef FMRX_TUNING
         if (const char *e = std::getenv("FMRX_FUSED_TUNE")) d.fused_tune = std::atoi(e);
         if (const char *e = std::getenv("FMRX_FE_MFMA_TUNE")) d.fe_mfma_tune = std::atoi(e);
@@ -92,6 +94,18 @@ Options &default_options()
         return d;
     }();
     return o;
+}
+
+std::mutex &options_mutex()
+{
+    static std::mutex m;
+    return m;
+}
+
+Options options_snapshot()
+{
+    std::lock_guard<std::mutex> lock(options_mutex());
+    return default_options();
 }
 
 int set_option_in(Options &o, const char *name, long value)
@@ -105,6 +119,7 @@ int set_option_in(Options &o, const char *name, long value)
 #endif
     if (pi == &o.fe_variant && value != 0 && value != 1) return fail(FMRX_EINVAL, "option fe_variant: 0 (mfma) or 1 (valu)");
     if (pi == &o.pll_mode && (value < 0 || value > 2)) return fail(FMRX_EINVAL, "option pll_mode: 0, 1 or 2");
+    if (pi == &o.demod && value != 0 && value != 1) return fail(FMRX_EINVAL, "option demod: 0 (the C++ reference's discriminator) or 1 (arctan)");
     if (pl) *pl = value;
     else *pi = static_cast<int>(value);
     return FMRX_OK;
@@ -158,10 +173,17 @@ const char *fmrx_version(void)
 #endif
 }
 
-int fmrx_set_option(const char *name, long value) { return set_option_in(default_options(), name, value); }
+// The process-wide defaults may be changed by one thread while another creates a handle (which copies them): writers and the
+// copy go through one mutex (options_snapshot); per-block paths only ever read a handle's own copy.
+int fmrx_set_option(const char *name, long value)
+{
+    std::lock_guard<std::mutex> lock(options_mutex());
+    return set_option_in(default_options(), name, value);
+}
 
 int fmrx_get_option(const char *name, long *value)
 {
+    std::lock_guard<std::mutex> lock(options_mutex());
     long *pl = nullptr;
     int *pi = nullptr;
     if (!value || !option_ref(default_options(), name, &pl, &pi)) return fail(FMRX_EINVAL, "unknown option '%s'", name ? name : "(null)");
@@ -318,9 +340,22 @@ int fmrx_convolve_block_resample_fir(float *y, const float *x, size_t n, const f
     FMRX_TRY(h2d(s.a.p + Hp, x, n * sizeof(float)));
     // polyphase-table kernels (bit-exact: the reference's operations in its order, kernels_resample.hip);
     // the LDS-resident-table form from 65 536 outputs per call unless the option resample_l2 is set
-    ResamplePlan plan;
-    FMRX_TRY(resample_plan_init(plan, h, static_cast<int>(taps), static_cast<int>(decim), static_cast<int>(upsamp)));
-    FMRX_TRY(resample_launch(plan, s.a.p + Hp, n, 0, s.b.p, default_options(), nullptr, false, /*exact=*/true));
+    // the plan (polyphase table, tap images: several device allocations and copies) is kept per thread and rebuilt only when
+    // the filter changes: a block-streaming caller passes the same taps every call (src/project.cpp:353)
+    struct PlanCache {
+        ResamplePlan plan;
+        std::vector<float> h;
+        unsigned decim = 0, upsamp = 0;
+    };
+    static thread_local PlanCache pc;
+    if (pc.decim != decim || pc.upsamp != upsamp || pc.h.size() != taps || std::memcmp(pc.h.data(), h, taps * sizeof(float)) != 0) {
+        pc.decim = pc.upsamp = 0;                              // invalid until the new plan is complete
+        FMRX_TRY(resample_plan_init(pc.plan, h, static_cast<int>(taps), static_cast<int>(decim), static_cast<int>(upsamp)));
+        pc.h.assign(h, h + taps);
+        pc.decim = decim;
+        pc.upsamp = upsamp;
+    }
+    FMRX_TRY(resample_launch(pc.plan, s.a.p + Hp, n, 0, s.b.p, options_snapshot(), nullptr, false, /*exact=*/true));
     FMRX_TRY(sync0());
     FMRX_TRY(d2h(y, s.b.p, n_out * sizeof(float)));
     // state refresh exactly as src/filter.cpp:218-222 (host copy): k = U-1; for
@@ -381,6 +416,26 @@ int fmrx_fm_demod(float *out, const float *I, const float *Q, size_t n, float *p
     FMRX_TRY(d2h(out, s.c.p, n * sizeof(float)));
     *prev_i = I[n - 1];
     *prev_q = Q[n - 1];
+    return FMRX_OK;
+}
+
+int fmrx_fm_demod_arctan(double *out, const double *I, const double *Q, size_t n, double *prev_phase)
+{
+    if (!out || !I || !Q || !prev_phase) return fail(FMRX_EINVAL, "fm_demod_arctan: null buffer");
+    if (n == 0) return FMRX_OK;
+    FMRX_TRY(require_device());
+    static thread_local DevBuf<double> di, dq, dout;
+    FMRX_TRY(di.ensure(n));
+    FMRX_TRY(dq.ensure(n));
+    FMRX_TRY(dout.ensure(n));
+    FMRX_TRY(h2d(di.p, I, n * sizeof(double)));
+    FMRX_TRY(h2d(dq.p, Q, n * sizeof(double)));
+    // the phase in front of the block only matters modulo 2 pi (np.unwrap's mod takes care of the turns it has accumulated)
+    FMRX_TRY(k_fm_demod_arctan_planar(di.p, dq.p, n, *prev_phase, dout.p, nullptr));
+    FMRX_TRY(d2h(out, dout.p, n * sizeof(double)));
+    double ph = *prev_phase;                                // the model's running (unwrapped) phase: prev + the steps, in order
+    for (size_t k = 0; k < n; k++) ph += out[k];
+    *prev_phase = ph;
     return FMRX_OK;
 }
 

@@ -110,7 +110,7 @@ int fmrx_channels_create_ex(fmrx_channels **out, const fmrx_params *p, int n_cha
         c->block_bytes = block_bytes;
         c->audio_channels = audio_channels;
         c->exact = 1;
-        c->opt = default_options();
+        c->opt = options_snapshot();
         auto body = [&]() -> int {
             FMRX_TRY(stereo_bank_create(&c->bank, *p, n_channels, audio_channels, block_bytes));
             c->n_audio = stereo_bank_n_audio(c->bank);
@@ -138,7 +138,7 @@ int fmrx_channels_create_ex(fmrx_channels **out, const fmrx_params *p, int n_cha
     c->n_channels = n_channels;
     c->device = device;
     c->block_bytes = block_bytes;
-    c->opt = default_options();
+    c->opt = options_snapshot();
     auto body = [&]() -> int {
         std::vector<float> h(p->rf_taps);
         design_lpf(static_cast<float>(p->rf_Fs), 100000.0f, p->rf_taps, h.data());        // src/project.cpp:50

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -61,10 +62,14 @@ struct Options {
     int pll_head = -1;             // "pll_head" / FMRX_PLL_HEAD: samples of a stream's first call walked serially (-1 = built-in)
     int pll_mode = 0;              // "pll_mode" / FMRX_PLL_MODE: stereo PLL of the specialised pipeline: 0 = parallel in time, fast math
                                    //   (default); 1 = serial, fast math; 2 = serial, glibc math (the cause-by-cause variants of DESIGN 2)
+    int demod = 0;                 // "demod" / FMRX_DEMOD: 0 = the C++ reference's discriminator (fmDemod, src/filter.cpp:248-266; default),
+                                   //   1 = the Python model's arctangent demodulator (fmDemodArctan, model/fmSupportLib.py:502-531), float64
     int fused_tune = 0;            // "fused_tune", "fe_mfma_tune": ablation variants, honoured only by a -DFMRX_TUNING build
     int fe_mfma_tune = 0;
 };
 Options &default_options();
+std::mutex &options_mutex();     // guards writes to the process-wide defaults and the copy a new handle takes
+Options options_snapshot();      // the defaults, copied under the mutex: what handle constructors use
 // name -> field; returns false for an unknown name
 bool option_ref(Options &o, const char *name, long **as_long, int **as_int);
 int set_option_in(Options &o, const char *name, long value);   // validates; FMRX_EINVAL for unknown names / values
@@ -230,6 +235,11 @@ int k_fm_demod_if(const float *d_if, size_t n, const float *d_prev, float *d_pre
                   hipStream_t s);
 int k_fm_demod_planar(const float *d_i, const float *d_q, size_t n, float prev_i, float prev_q, float *d_demod,
                       hipStream_t s);
+// the model's arctangent demodulator (fmSupportLib.py:502-531), float64: out[k] = unwrap(atan2(Q[k], I[k]) - phase of the sample in
+// front); planar double in / double out with the running phase `prev_phase` in front of sample 0 (stage API), and interleaved
+// float IF in / float out with IF[-1] = *d_prev (pipeline option "demod" = 1)
+int k_fm_demod_arctan_planar(const double *d_i, const double *d_q, size_t n, double prev_phase, double *d_out, hipStream_t s);
+int k_fm_demod_arctan_if(const float *d_if, size_t n, const float *d_prev, float *d_demod, hipStream_t s);
 int k_u8_to_f32(const uint8_t *d_raw, size_t n, float *d_out, hipStream_t s);
 int k_deinterleave(const float *d_iq, size_t n_pairs, float *d_i, float *d_q, hipStream_t s);
 int k_split_if(const float *d_if, size_t n, float *d_i, float *d_q, hipStream_t s);

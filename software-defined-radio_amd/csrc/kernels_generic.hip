@@ -131,6 +131,44 @@ __global__ void demod_planar_kernel(const float *__restrict__ I, const float *__
     out[k] = demod_one(I[k], Q[k], pi, pq);
 }
 
+// ---- arctangent demodulator of the reference's Python model (model/fmSupportLib.py:502-531), float64 --------------
+// The model walks the samples: phase = atan2(Q, I); [prev, phase] = np.unwrap([prev, phase]); out = phase - prev; prev = phase.
+// np.unwrap of a pair adds  ddmod - dd  to the second element,  dd = phase - prev,  ddmod = mod(dd + pi, 2 pi) - pi  (pi
+// instead of -pi when dd > 0), nothing where |dd| < pi: out[k] is the phase step wrapped into (-pi, pi].  The model's running
+// phase is the UNWRAPPED one (it grows with the stream); a step computed from the wrapped phases of the two samples is the
+// same real number, and differs from the model's float64 result by the rounding of that growing phase (1e-12 after 1e4 rad):
+// every output is independent, one thread each.  (C++ reference: the discriminator fmDemod; this variant is model-only.)
+__device__ inline double unwrap_step(double dd)
+{
+    const double pi = 3.141592653589793, two_pi = 6.283185307179586;
+    double r = fmod(dd + pi, two_pi);                 // np.mod: the result has the sign of the divisor
+    if (r < 0.0) r += two_pi;
+    double ddmod = r - pi;
+    if (ddmod == -pi && dd > 0.0) ddmod = pi;
+    return fabs(dd) < pi ? dd : ddmod;
+}
+
+__global__ void demod_arctan_planar_kernel(const double *__restrict__ I, const double *__restrict__ Q, size_t n, double prev_phase,
+                                           double *__restrict__ out)
+{
+    const size_t k = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const double ph = atan2(Q[k], I[k]);
+    const double pv = k ? atan2(Q[k - 1], I[k - 1]) : prev_phase;
+    out[k] = unwrap_step(ph - pv);
+}
+
+__global__ void demod_arctan_if_kernel(const float2 *__restrict__ z, size_t n, const float2 *__restrict__ prev, float *__restrict__ out)
+{
+    const size_t k = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float2 c = z[k];
+    const float2 p = k ? z[k - 1] : *prev;
+    const double ph = atan2(static_cast<double>(c.y), static_cast<double>(c.x));
+    const double pv = atan2(static_cast<double>(p.y), static_cast<double>(p.x));
+    out[k] = static_cast<float>(unwrap_step(ph - pv));
+}
+
 // ---- element-wise helpers ------------------------------------------------------------
 __global__ void u8_to_f32_kernel(const uint8_t *__restrict__ raw, size_t n, float *__restrict__ out)
 {
@@ -261,6 +299,23 @@ int k_fm_demod_if(const float *d_if, size_t n, const float *d_prev, float *d_pre
                            reinterpret_cast<const float2 *>(d_if), n, reinterpret_cast<const float2 *>(d_prev),
                            reinterpret_cast<float2 *>(d_prev_out), d_demod);
     FMRX_LAUNCH_CHECK("demod_if");
+    return FMRX_OK;
+}
+
+int k_fm_demod_arctan_planar(const double *d_i, const double *d_q, size_t n, double prev_phase, double *d_out, hipStream_t s)
+{
+    if (n == 0) return FMRX_OK;
+    hipLaunchKernelGGL(demod_arctan_planar_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, d_i, d_q, n, prev_phase, d_out);
+    FMRX_LAUNCH_CHECK("demod_arctan_planar");
+    return FMRX_OK;
+}
+
+int k_fm_demod_arctan_if(const float *d_if, size_t n, const float *d_prev, float *d_demod, hipStream_t s)
+{
+    if (n == 0) return FMRX_OK;
+    hipLaunchKernelGGL(demod_arctan_if_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, reinterpret_cast<const float2 *>(d_if), n,
+                       reinterpret_cast<const float2 *>(d_prev), d_demod);
+    FMRX_LAUNCH_CHECK("demod_arctan_if");
     return FMRX_OK;
 }
 

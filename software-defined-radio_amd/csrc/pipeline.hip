@@ -74,6 +74,7 @@ struct fmrx_pipeline {
     hipStream_t ov_stream[3] = {};   // front, PLL, output
     hipEvent_t ov_done[3][2] = {};   // [stage][parity]: the stage of the last call of that parity has finished
     hipEvent_t ov_entry = nullptr;   // the caller's stream at the call: what it did with the previous output is over
+    bool ov_ready = false;           // overlap_setup has completed
     int ov_active = 0;               // the regime (option value) of the last call
     int last_set = 0;                // buffer set the last call used (read_tap)
     // state_stereofilt: the mixer output's last Hm samples (index Hm+g holds sample g < 0), written by one call
@@ -205,7 +206,7 @@ int fmrx_pipeline_create(fmrx_pipeline **out, const fmrx_params *p, int channels
     FMRX_HIP(hipSetDevice(device));
 
     fmrx_pipeline *pl = new fmrx_pipeline;
-    pl->opt = default_options();
+    pl->opt = options_snapshot();
     pl->p = *p;
     pl->channels = channels;
     pl->device = device;
@@ -363,16 +364,21 @@ int fmrx_pipeline_set_force_generic(fmrx_pipeline *pl, int on)
 // internal streams, events and the second buffer set of option overlap_calls, on first use
 static int overlap_setup(fmrx_pipeline *pl)
 {
-    if (pl->ov_stream[0]) return FMRX_OK;
+    if (pl->ov_ready) return FMRX_OK;
+    // every handle is created only where it is still missing: a call that failed half way (out of memory, say) is simply
+    // continued by the next one, nothing is created twice and nothing leaks (destroy frees whatever exists)
     const size_t n_if = (pl->max_bytes / 2) / pl->p.rf_decim;
-    FMRX_TRY(pl->carrier1.alloc(pl->carrier.n));
-    FMRX_TRY(pl->bpf1.alloc(pl->bpf.n));
-    FMRX_TRY(pl->pll1.alloc(pl->pll.n));
-    for (auto &b : pl->lti_rec) FMRX_TRY(b.alloc(pll_parallel_lti_floats(n_if) + 2));
+    FMRX_TRY(pl->carrier1.ensure(pl->carrier.n));
+    FMRX_TRY(pl->bpf1.ensure(pl->bpf.n));
+    FMRX_TRY(pl->pll1.ensure(pl->pll.n));
+    for (auto &b : pl->lti_rec) FMRX_TRY(b.ensure(pll_parallel_lti_floats(n_if) + 2));
     for (auto &q : pl->ov_done)
-        for (auto &e : q) FMRX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    FMRX_HIP(hipEventCreateWithFlags(&pl->ov_entry, hipEventDisableTiming));
-    for (int i = 2; i >= 0; i--) FMRX_HIP(hipStreamCreateWithFlags(&pl->ov_stream[i], hipStreamNonBlocking));
+        for (auto &e : q)
+            if (!e) FMRX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (!pl->ov_entry) FMRX_HIP(hipEventCreateWithFlags(&pl->ov_entry, hipEventDisableTiming));
+    for (auto &st : pl->ov_stream)
+        if (!st) FMRX_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    pl->ov_ready = true;
     return FMRX_OK;
 }
 
@@ -415,8 +421,11 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
     bool hist_done = false;
     pl->demod_valid = true;
     const bool mfma = pl->opt.fe_variant == 0;
+    // option demod = 1: the model's arctangent demodulator on the IF stream (materialised for it), instead of the front-end kernels' own discriminator
+    const bool arctan = pl->opt.demod == 1;
+    const bool keep_if = pl->keep_if || arctan;
     // option overlap_calls: front | PLL | output stage of the stereo chain of consecutive calls on internal streams (see the struct)
-    const bool ovl = pl->opt.overlap_calls != 0 && pl->channels == 2 && !pl->resample && !pl->force_generic && !pl->keep_if &&
+    const bool ovl = pl->opt.overlap_calls != 0 && pl->channels == 2 && !pl->resample && !pl->force_generic && !keep_if &&
                      !pl->profiling && pl->opt.pll_mode == 0 && mfma && n_if >= static_cast<size_t>(pl->Hd) &&
                      fe_mfma_available(pl->fe, d_iq, n, hist) && stereo_out_available(p.audio_taps, p.audio_decim);
     const int regime = ovl ? pl->opt.overlap_calls : 0;
@@ -442,7 +451,7 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
             FMRX_HIP(hipStreamWaitEvent(so, pl->ov_entry, 0));
         }
     }
-    if (pl->channels == 1 && !pl->resample && !pl->force_generic && !pl->keep_if && mfma &&
+    if (pl->channels == 1 && !pl->resample && !pl->force_generic && !keep_if && mfma &&
         n_if >= static_cast<size_t>(pl->Hd) && static_cast<long>(n_au) >= pl->opt.fused_min_audio &&
         mono_fused_available(pl->fe, pl->audio, d_iq, n, hist)) {
         // ---- RF_FrontEnd + RF_MONO of modes 0/1 in one kernel (kernels_fe_mfma.hip): the discriminator
@@ -479,23 +488,26 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
         // the kernel copies it there itself (it is the tail of the previous block's buffer)
         const bool want_front = !(pl->channels == 1 && !pl->resample) && n_if >= static_cast<size_t>(pl->Hd);
         FMRX_TRY(fe_mfma_launch(pl->fe, d_iq, n, hist, pl->prev_override ? prev : nullptr, demod,
-                                pl->keep_if ? pl->ifb.p : nullptr, prev_next,
+                                keep_if ? pl->ifb.p : nullptr, prev_next,
                                 hist_done ? hist_next : nullptr, pl->opt, sf, want_front ? hist_end - pl->Hd : nullptr,
                                 want_front ? dbuf : nullptr, pl->Hd));
         if (want_front) pl->demod_front[cur] = true;
-        pl->if_valid = pl->keep_if;
+        pl->if_valid = keep_if;
     } else if (!pl->force_generic && fe_fused_available(pl->fe, d_iq, n)) {
         // one kernel; the IF stream is written only when somebody asked to look at it, and the kernel
         // also leaves the stream's last bytes (I_state/Q_state, filter.cpp:182-187) for the next block
         hist_done = n_bytes >= static_cast<size_t>(hb);
         FMRX_TRY(fe_demod_launch(pl->fe, d_iq, n, hist, pl->prev_override ? prev : nullptr, demod,
-                                 pl->keep_if ? pl->ifb.p : nullptr, prev_next, hist_done ? hist_next : nullptr, pl->opt, s));
-        pl->if_valid = pl->keep_if;
+                                 keep_if ? pl->ifb.p : nullptr, prev_next, hist_done ? hist_next : nullptr, pl->opt, s));
+        pl->if_valid = keep_if;
     } else {
         FMRX_TRY(fe_launch(pl->fe, d_iq, n, hist, pl->ifb.p, pl->opt, s, pl->force_generic));
         FMRX_TRY(k_fm_demod_if(pl->ifb.p, n_if, prev, prev_next, demod, 0, s));
         pl->if_valid = true;
     }
+    // fmDemodArctan (model/fmSupportLib.py:502-531) over the IF stream, IF[-1] = the carried prev_i / prev_q (their phase is the
+    // model's state_phase modulo 2 pi; zeros at the start of a stream: atan2(0, 0) = 0 = the model's initial phase)
+    if (arctan) FMRX_TRY(k_fm_demod_arctan_if(pl->ifb.p, n_if, prev, demod, s));
     pl->prev_cur ^= 1;
     pl->prev_override = false;
     pl->fe_cur ^= 1;
@@ -575,7 +587,7 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
                 FMRX_TRY(k_fm_pll_parallel(carrier_b + head, n_if - head, pll_b + head, pl->pll_state.p, 19e3f,
                                            static_cast<float>(p.if_Fs), 2.0f, 0.0f, 0.01f, pl->pll_scratch.p, pl->opt, sf,
                                            pl->pll_off + static_cast<double>(head), 1, lti));
-            if (ovl) {
+            if (ovl) {   // read-after-write: the lanes read this call's carrier / chunk records, which the front wrote on its own stream
                 FMRX_HIP(hipEventRecord(pl->ov_done[0][cur], sf));
                 FMRX_HIP(hipStreamWaitEvent(sp, pl->ov_done[0][cur], 0));
             }
@@ -587,7 +599,7 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
                                            static_cast<float>(p.if_Fs), 2.0f, 0.0f, 0.01f, pl->pll_scratch.p, pl->opt, sp,
                                            pl->pll_off + static_cast<double>(head), ovl ? 2 : 3, lti));
             pl->pll_warm = true;
-            if (so != sp) {
+            if (so != sp) {   // read-after-write: the output stage reads the NCO values and the PLL state the lanes / repair left
                 FMRX_HIP(hipEventRecord(pl->ov_done[1][cur], sp));
                 FMRX_HIP(hipStreamWaitEvent(so, pl->ov_done[1][cur], 0));
             }

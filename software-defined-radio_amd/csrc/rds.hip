@@ -413,8 +413,12 @@ int fmrx_rds_process_dev(fmrx_rds *r, const float *d_demod, size_t n, void *stre
     if (!r || !d_demod) return fail(FMRX_EINVAL, "rds_process_dev: null argument");
     if (n == 0 || n > r->max_n) return fail(FMRX_EINVAL, "rds_process_dev: block of %zu samples (max %zu)", n, r->max_n);
     if ((n * r->p.upsamp) % r->p.decim) return fail(FMRX_EINVAL, "rds_process_dev: n*upsamp = %zu not a multiple of decim %d", n * r->p.upsamp, r->p.decim);
-    if (n < static_cast<size_t>(r->Hc) || n * r->p.upsamp / r->p.decim < static_cast<size_t>(r->Hr))
-        return fail(FMRX_EINVAL, "rds_process_dev: block shorter than the filter histories");
+    // every carried history is refreshed by a copy of its buffer's tail to its front (rds_tail_kernel): the block must be at
+    // least as long as each of them, or source and destination of that copy overlap
+    if (n < static_cast<size_t>(r->Hc) || n < static_cast<size_t>(r->Hx) || n < static_cast<size_t>(r->Hm) ||
+        n * r->p.upsamp / r->p.decim < static_cast<size_t>(r->Hr))
+        return fail(FMRX_EINVAL, "rds_process_dev: block of %zu samples is shorter than a filter history (%d / %d / %d input samples, %d resampled)",
+                    n, r->Hx, r->Hc, r->Hm, r->Hr);
     FMRX_HIP(hipSetDevice(r->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const fmrx_rds_params &p = r->p;

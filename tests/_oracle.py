@@ -3,7 +3,8 @@
 * ``Oracle``  -> oracle/liboracle.so   (our C restatement, oracle/fm_oracle.c)
 * ``Ref``     -> oracle/_ref/libfmref.so (the reference's own src/filter.cpp +
   src/iofunc.cpp behind oracle/ref_shim.cpp; exists only where it was built
-  from /root/reference, i.e. in the build container; travels as a binary)
+  from /root/reference, i.e. in the build container: oracle/_ref/ is git-ignored
+  and gpurun-ignored, it does not travel to the GPU box)
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
 this module.  The product (software-defined-radio_amd) never does.

@@ -151,3 +151,54 @@ def test_stereo_bank_exact_256_channels_two_seconds(fmrx, oracle):
     assert hashlib.sha256(R[0].tobytes()).digest() == g["audio_r_sha256"].tobytes()
     # the signals really are different receivers' (not 256 copies)
     assert len({hashlib.sha256(L[c].tobytes()).digest() for c in range(N)}) == N
+
+
+def test_eight_pipelines_on_eight_streams(fmrx, oracle):
+    """BASELINE configs[4] on the hardware that exists: the eight independent 2.4 MS/s mono channels that an 8-GPU node runs
+    one per GPU (seeds 0x3D74 + c, as bench.py's ranks use them), here as eight pipeline handles on eight HIP streams of ONE
+    device, their calls interleaved block by block.  Every channel's PCM and float audio must be bit-identical to the same
+    handle type running that channel alone on one stream (handles share nothing), and within the mono tolerance of the
+    oracle streaming that channel."""
+    import torch
+    nch, nblk, bb = 8, 2, 2 * 1024000
+    iqs = [oracle.synth_fm_u8(bb // 2 * nblk, seed=0x3D74 + c) for c in range(nch)]
+    d_iq = [torch.from_numpy(x).cuda() for x in iqs]
+    na = 1024000 // 50
+
+    def run(c, stream, pl, d_pcm, d_f32):
+        for b in range(nblk):
+            pl.process_dev(d_iq[c].data_ptr() + b * bb, bb, d_f32[b].data_ptr(), d_pcm[b].data_ptr(), wrap=True, stream=stream.cuda_stream)
+
+    # alone: one channel after the other, one stream
+    alone = []
+    s0 = torch.cuda.Stream()
+    for c in range(nch):
+        pl = fmrx.Pipeline(0, 1, max_block_bytes=bb)
+        d_pcm, d_f32 = torch.zeros(nblk, na, dtype=torch.int16, device="cuda"), torch.zeros(nblk, na, dtype=torch.float32, device="cuda")
+        run(c, s0, pl, d_pcm, d_f32)
+        s0.synchronize()
+        alone.append((d_pcm.cpu().numpy(), d_f32.cpu().numpy()))
+        pl.close()
+    # together: eight handles, eight streams, calls interleaved
+    streams = [torch.cuda.Stream() for _ in range(nch)]
+    pls = [fmrx.Pipeline(0, 1, max_block_bytes=bb) for _ in range(nch)]
+    outs = [(torch.zeros(nblk, na, dtype=torch.int16, device="cuda"), torch.zeros(nblk, na, dtype=torch.float32, device="cuda")) for _ in range(nch)]
+    torch.cuda.synchronize()
+    for b in range(nblk):
+        for c in range(nch):
+            pls[c].process_dev(d_iq[c].data_ptr() + b * bb, bb, outs[c][1][b].data_ptr(), outs[c][0][b].data_ptr(), wrap=True,
+                               stream=streams[c].cuda_stream)
+    torch.cuda.synchronize()
+    for c in range(nch):
+        bits_equal(outs[c][0].cpu().numpy(), alone[c][0], f"pcm, channel {c}")
+        bits_equal(outs[c][1].cpu().numpy(), alone[c][1], f"audio, channel {c}")
+        ref = oracle.pipeline(0, 1)
+        for b in range(nblk):
+            want = ref.process(iqs[c][b * bb:(b + 1) * bb])["audio"]
+            err = float(np.sqrt(np.mean((outs[c][1][b].cpu().numpy().astype(np.float64) - want) ** 2)))
+            assert err <= 1e-4, (c, b, err)
+            d = np.abs(outs[c][0][b].cpu().numpy().astype(np.int32) - oracle.pcm16(want).astype(np.int32))
+            assert d.max() <= 1
+    assert len({hashlib.sha256(a[0].tobytes()).digest() for a in alone}) == nch
+    for pl in pls:
+        pl.close()

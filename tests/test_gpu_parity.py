@@ -1242,3 +1242,47 @@ def test_spec_mode_pipeline(fmrx, oracle, U, D, channels, fe):
         got = plb.process(big)["audio"]
         assert len(got) == len(want) >= 65536
         assert_audio_close(got, want, f"spec mode {U}/{D}, {nbig} blocks in one call")
+
+
+def test_arctan_demodulator(fmrx, oracle):
+    """BASELINE.json's "arctan demod": fmDemodArctan exists only in the reference's Python model (model/fmSupportLib.py:502-531;
+    the C++ receiver uses the discriminator).  Stage function (float64) against tests/golden/arctan.npz, which the reference's
+    own fmSupportLib.py produced in the build container: phase steps within 1e-9 (the model rounds at the size of its growing
+    unwrapped phase, ~1e-12; the device's atan2 differs from the host's by ulps), carried phase within 1e-8, over three blocks
+    with state and over a sequence that walks np.unwrap's branches.  Then the pipeline option demod = arctan: the
+    discriminator tap equals the model's output on the oracle's IF samples to float32 rounding, block after block, and the
+    audio is the oracle's audio FIR of that stream."""
+    g = np.load(os.path.join(G, "arctan.npz"))
+    phase = 0.0
+    for b in range(int(g["nblk"][0])):
+        d, phase = fmrx.fmDemodArctan(g[f"b{b}_if_i"], g[f"b{b}_if_q"], phase)
+        assert np.abs(d - g[f"b{b}_demod"]).max() <= 1e-9, b
+        assert abs(phase - float(g[f"b{b}_phase"][0])) <= 1e-8
+    d, ph = fmrx.fmDemodArctan(g["edge_i"], g["edge_q"], float(g["edge_prev"][0]))
+    # a step within 1e-9 of +-pi may legitimately wrap the other way: compare modulo 2 pi
+    e = np.abs(d - g["edge_demod"])
+    e = np.minimum(e, np.abs(e - 2 * np.pi))
+    assert e.max() <= 1e-9
+    p = oracle.mode_params(0, 101, 101, 101)
+    iq = oracle.synth_fm_u8(p.block_bytes // 2 * int(g["nblk"][0]), rf_Fs=p.rf_Fs, seed=int(g["seed"][0]))
+    h_au = oracle.impulse_response_lpf(240e3, 16e3, 101)
+    for fe in ("mfma", "valu"):
+        pl = fmrx.Pipeline(0, 1)
+        pl.set_option("fe_variant", fe)
+        pl.set_option("demod", "arctan")
+        st = np.zeros(100, np.float32)
+        for b in range(int(g["nblk"][0])):
+            out = pl.process(iq[b * p.block_bytes:(b + 1) * p.block_bytes])
+            dem = pl.read_tap("demod")
+            want = g[f"b{b}_demod"]
+            # the specialised front ends' IF samples are within 6e-7 of the oracle's (FE_REL_RMS): a phase moves by that over the
+            # sample's magnitude (small in the first samples of a stream, 0.8 afterwards), twice (two samples per step), plus
+            # the float32 rounding of a value <= pi
+            mag = np.hypot(g[f"b{b}_if_i"], g[f"b{b}_if_q"]).astype(np.float64)
+            mag = np.minimum(mag, np.concatenate([[mag[0]], mag[:-1]]))
+            tol = 5e-7 + 1.2e-6 / np.maximum(mag, 1e-3)
+            assert (np.abs(dem - want) <= tol).all(), (fe, b, np.abs(dem - want).max())
+            y, st = oracle.convolve_block_fast_fir(want.astype(np.float32), h_au, st, 5)
+            assert_audio_close(out["audio"], y, f"{fe} block {b}")
+    with pytest.raises(fmrx.FmrxError):
+        pl.set_option("demod", 2)
