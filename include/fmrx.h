@@ -325,7 +325,11 @@ FMRX_API int fmrx_channels_create(fmrx_channels **out, const fmrx_params *p, int
  *                   to run stereo within the 1e-4 bound at speed: the recurrence cannot be cut in time without leaving
  *                   the reference's trajectory, but receivers are independent (one STATES set
  *                   each, src/project.cpp:455-468).
- *                   0 = the specialised kernels (fmrx_channels_create's; mono only).
+ *                   0 = the specialised kernels: mono, fmrx_channels_create's bank; stereo, the matrix-core front end, one fused
+ *                   multiply-add per tap in the band-pass pair and the audio FIRs, and the PLL's fast recurrence (closed-form phase
+ *                   detector, hardware sine / cosine) walked by one lane per channel -- the error bound of the default
+ *                   single-stream stereo path (1e-4 for a stream's first 0.13 s, 0.06 ulp(trigArg(t)) after; mono sum 2e-6)
+ *                   at several times the exact bank's rate.
  * Outputs: audio_f32 [n_channels][audio_channels][n_audio] (stereo: left, then right), pcm16
  * [n_channels][n_audio][audio_channels] (stereo: interleaved L,R as the writer at src/project.cpp:292-302). */
 FMRX_API int fmrx_channels_create_ex(fmrx_channels **out, const fmrx_params *p, int n_channels, int audio_channels, int exact,

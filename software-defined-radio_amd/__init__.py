@@ -486,7 +486,8 @@ class Channels:
 
     audio_channels: 1 mono, 2 stereo (the reference's second command-line argument).  exact=True: every stage in the
     reference's float32 evaluation order, fmPLL as the serial recurrence with glibc's functions, one lane per channel --
-    audio equals the compiled reference's bit for bit (stereo banks are always exact)."""
+    audio equals the compiled reference's bit for bit.  exact=False with audio_channels=2: the fast stereo bank (matrix-core
+    front end, fma FIRs, the PLL's fast recurrence one lane per channel; the default stereo path's error envelope)."""
 
     def __init__(self, mode=0, n_channels=1, rf_taps=101, base_audio_taps=101, block_bytes=None, device=0, params: Params | None = None,
                  audio_channels=1, exact=False, stereo_taps=101):

@@ -60,6 +60,8 @@ bool option_ref(Options &o, const char *name, long **as_long, int **as_int)
     else if (n == "pll_align") *as_int = &o.pll_align;
     else if (n == "pll_mode") *as_int = &o.pll_mode;
     else if (n == "demod") *as_int = &o.demod;
+    else if (n == "bank_streams") *as_int = &o.bank_streams;
+    else if (n == "bank_fe_wgs") *as_int = &o.bank_fe_wgs;
     else if (n == "resample_chains") *as_int = &o.resample_chains;
     else if (n == "overlap_calls") *as_int = &o.overlap_calls;
     else if (n == "fused_tune") *as_int = &o.fused_tune;
@@ -86,6 +88,8 @@ Options &default_options()
         if (const char *e = std::getenv("FMRX_PLL_START")) d.pll_start = std::atoi(e);
         if (const char *e = std::getenv("FMRX_PLL_ALIGN")) d.pll_align = std::atoi(e);
         if (const char *e = std::getenv("FMRX_PLL_MODE")) d.pll_mode = std::atoi(e);
+        if (const char *e = std::getenv("FMRX_BANK_STREAMS")) d.bank_streams = std::atoi(e);
+        if (const char *e = std::getenv("FMRX_BANK_FE_WGS")) d.bank_fe_wgs = std::atoi(e);
         if (const char *e = std::getenv("FMRX_DEMOD")) d.demod = std::strcmp(e, "arctan") == 0 ? 1 : std::atoi(e);
 #ifdef FMRX_TUNING
         if (const char *e = std::getenv("FMRX_FUSED_TUNE")) d.fused_tune = std::atoi(e);

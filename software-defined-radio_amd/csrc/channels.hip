@@ -100,7 +100,6 @@ int fmrx_channels_create_ex(fmrx_channels **out, const fmrx_params *p, int n_cha
         const size_t unit4 = static_cast<size_t>(2) * p->rf_decim * p->audio_decim;
         if (block_bytes == 0 || block_bytes % unit4 || block_bytes % 16)
             return fail(FMRX_EINVAL, "channels_create: block_bytes must be a multiple of 16 and of 2*rf_decim*audio_decim = %zu", unit4);
-        if (!exact) return fail(FMRX_EINVAL, "channels_create: stereo banks run in the reference's evaluation order (exact = 1)");
         FMRX_TRY(require_device());
         FMRX_HIP(hipSetDevice(device));
         fmrx_channels *c = new fmrx_channels;
@@ -109,10 +108,10 @@ int fmrx_channels_create_ex(fmrx_channels **out, const fmrx_params *p, int n_cha
         c->device = device;
         c->block_bytes = block_bytes;
         c->audio_channels = audio_channels;
-        c->exact = 1;
+        c->exact = exact ? 1 : 0;
         c->opt = options_snapshot();
         auto body = [&]() -> int {
-            FMRX_TRY(stereo_bank_create(&c->bank, *p, n_channels, audio_channels, block_bytes));
+            FMRX_TRY(stereo_bank_create(&c->bank, *p, n_channels, audio_channels, c->exact, block_bytes));
             c->n_audio = stereo_bank_n_audio(c->bank);
             FMRX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
             FMRX_TRY(c->pcm_out.alloc(c->n_audio * n_channels * audio_channels));

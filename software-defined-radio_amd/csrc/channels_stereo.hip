@@ -198,42 +198,60 @@ struct BpX {
     static_assert(NW % 4 == 0, "window must be whole 16-byte chunks");
 };
 
-template <int T, int G>
-__device__ __forceinline__ void bpx_step(const float (&w)[BpX<T>::NW], const float *__restrict__ table, f2 (&acc)[kR], f16v &hA,
-                                         f16v &hB)
+// The taps of consecutive steps overlap: step u needs the pairs P[u .. u+7] of the padded table P[m] = (h_st, h_car)[m - (R-1)]
+// (zero outside the filter), i.e. one NEW pair per step.  They are fetched in groups of eight (one s_load_dwordx16 per EIGHT
+// steps) into three rotating SGPR groups: at the start of block g the groups g and g+1 are resident and g+2 is requested --
+// scalar loads return out of order, so every wait is for all of them, and a load requested eight steps (~500 cycles) ahead
+// has long arrived (one load per step, waited for a step later, left the vector ALU idle half the time).
+template <int T, bool EXACT, int G>
+__device__ __forceinline__ void bpx_block(const float (&w)[BpX<T>::NW], const float *__restrict__ table, f2 (&acc)[kR], f16v &g0,
+                                          f16v &g1, f16v &g2)
 {
     using C = BpX<T>;
-    if constexpr (G < C::W) {
-        float hq[16];
-        if constexpr (G % 2 == 0) {
-            CHS_TAPS_WAIT(hA);
-            if constexpr (G + 1 < C::W) CHS_TAPS_ISSUE(hB, table, (G + 1) * 64);
+    constexpr int NBLK = (C::W + 7) / 8;
+    if constexpr (G < NBLK) {
+        // groups G (cur), G + 1 (next) resident after this wait; G + 2 requested behind it into the group G - 1 used
+        f16v &cur = G % 3 == 0 ? g0 : (G % 3 == 1 ? g1 : g2);
+        f16v &nxt = (G + 1) % 3 == 0 ? g0 : ((G + 1) % 3 == 1 ? g1 : g2);
+        f16v &fut = (G + 2) % 3 == 0 ? g0 : ((G + 2) % 3 == 1 ? g1 : g2);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(cur), "+s"(nxt));
+        if constexpr (G + 2 <= NBLK) CHS_TAPS_ISSUE(fut, table, (G + 2) * 64);
+        float hc[16], hn[16];
 #pragma unroll
-            for (int k = 0; k < 16; k++) hq[k] = hA[k];
-        } else {
-            CHS_TAPS_WAIT(hB);
-            if constexpr (G + 1 < C::W) CHS_TAPS_ISSUE(hA, table, (G + 1) * 64);
-#pragma unroll
-            for (int k = 0; k < 16; k++) hq[k] = hB[k];
+        for (int k = 0; k < 16; k++) {
+            hc[k] = cur[k];
+            hn[k] = nxt[k];
         }
-        constexpr int i = C::W - 1 - G;
-        const float x = w[i + C::LEAD];
 #pragma unroll
-        for (int r = 0; r < kR; r++) {
-            const int n = r + (T - 1) - i;
-            if (n >= 0 && n < T) {
-                const f2 prod = (f2){x, x} * (f2){hq[2 * r], hq[2 * r + 1]};
-                acc[r] = acc[r] + prod;
+        for (int e = 0; e < 8; e++) {
+            const int u = 8 * G + e;
+            if (u < C::W) {
+                const int i = C::W - 1 - u;
+                const float x = w[i + C::LEAD];
+#pragma unroll
+                for (int r = 0; r < kR; r++) {
+                    const int n = r + (T - 1) - i;
+                    if (n >= 0 && n < T) {
+                        const int m = e + r;                       // pair P[8 G + m]: this group for m < 8, the next one after
+                        const float hs = m < 8 ? hc[2 * m] : hn[2 * (m - 8)], hcar = m < 8 ? hc[2 * m + 1] : hn[2 * (m - 8) + 1];
+                        if constexpr (EXACT) {
+                            const f2 prod = (f2){x, x} * (f2){hs, hcar};
+                            acc[r] = acc[r] + prod;
+                        } else {   // the fast bank: one fused multiply-add per tap (float32-rounding-equal, as the single-stream kernels)
+                            acc[r] = __builtin_elementwise_fma((f2){x, x}, (f2){hs, hcar}, acc[r]);
+                        }
+                    }
+                }
             }
-        }
 #pragma unroll
-        for (int r = 0; r < kR; r++) asm volatile("" : "+v"(acc[r]));
-        bpx_step<T, G + 1>(w, table, acc, hA, hB);
+            for (int r = 0; r < kR; r++) asm volatile("" : "+v"(acc[r]));
+        }
+        bpx_block<T, EXACT, G + 1>(w, table, acc, g0, g1, g2);
     }
 }
 
-template <int T>
-__global__ __launch_bounds__(64) void chs_bpf_exact_kernel(const float *__restrict__ demod, long dpitch, int Hd, long k_lo, long n_if,
+template <int T, bool EXACT>
+__global__ __launch_bounds__(64) void chs_bpf_kernel(const float *__restrict__ demod, long dpitch, int Hd, long k_lo, long n_if,
                                                              long wgs_per_channel, const float *__restrict__ table,
                                                              float *__restrict__ y_st, float *__restrict__ y_car, long ypitch)
 {
@@ -256,9 +274,10 @@ __global__ __launch_bounds__(64) void chs_bpf_exact_kernel(const float *__restri
     f2 acc[R];
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = (f2){0.0f, 0.0f};
-    f16v hA, hB;
-    CHS_TAPS_ISSUE(hA, table, 0);
-    bpx_step<T, 0>(w, table, acc, hA, hB);
+    f16v g0, g1, g2;
+    CHS_TAPS_ISSUE(g0, table, 0);
+    CHS_TAPS_ISSUE(g1, table, 64);
+    bpx_block<T, EXACT, 0>(w, table, acc, g0, g1, g2);
     float *ds = y_st + c * ypitch + k0, *dc = y_car + c * ypitch + k0;
     if (k0 + R <= n_if) {
         reinterpret_cast<f4 *>(ds)[0] = (f4){acc[0].x, acc[1].x, acc[2].x, acc[3].x};
@@ -279,7 +298,8 @@ __global__ __launch_bounds__(64) void chs_bpf_exact_kernel(const float *__restri
 // PLL[k+1] = cosf(trigArg[k]*ncoScale + phaseAdjust) (src/filter.cpp:72) is not on the recurrence's chain: the lanes leave the
 // raw trigArg of every step, this kernel turns a chunk's row segment into finished NCO values in place, four per thread
 // (glibc's cosf: the branch-free form when the whole wave's arguments are ordinary, i.e. always but in a stream's first 120 samples).
-__global__ __launch_bounds__(256) void chs_nco_exact_kernel(float *__restrict__ trig, long ypitch, long k_lo, long k_hi, long wgs_per_channel,
+template <bool EXACT>
+__global__ __launch_bounds__(256) void chs_nco_kernel(float *__restrict__ trig, long ypitch, long k_lo, long k_hi, long wgs_per_channel,
                                                              float nco_scale, float phase_adjust)
 {
     __shared__ uint32_t w24[24];
@@ -296,7 +316,13 @@ __global__ __launch_bounds__(256) void chs_nco_exact_kernel(float *__restrict__ 
     bool ok = true;
 #pragma unroll
     for (int i = 0; i < 4; i++) ok = ok && glibc235::sincosf_large_ok(a[i]);
-    if (!__any(!ok)) {
+    if (!EXACT) {   // the fast bank: one argument reduction in double, the hardware cosine (kernels_pll.hip: nco_out<kFast>)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const double rev = static_cast<double>(a[i]) * 0.15915494309189533577;
+            o[i] = __builtin_amdgcn_cosf(static_cast<float>(rev - rint(rev)));
+        }
+    } else if (!__any(!ok)) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             float sn;
@@ -338,7 +364,7 @@ struct OutX {
     __host__ __device__ static constexpr int idx(int j) { return j + j / SEG; }
 };
 
-template <int T, int D, bool STEREO, int G>
+template <int T, int D, bool STEREO, bool EXACT, int G>
 __device__ __forceinline__ void outx_step(const f2 *__restrict__ wl, const float *__restrict__ table, f2 (&acc)[kR], f16v &hA, f16v &hB)
 {
     using C = OutX<T, D>;
@@ -366,7 +392,9 @@ __device__ __forceinline__ void outx_step(const f2 *__restrict__ wl, const float
                     const int n = r * D + (T - 1) - jj;
                     if (n >= 0 && n < T) {
                         const float h = hq[8 * e + r];
-                        if constexpr (STEREO) {
+                        if constexpr (!EXACT) {
+                            acc[r] = __builtin_elementwise_fma(w, (f2){h, h}, acc[r]);
+                        } else if constexpr (STEREO) {
                             const f2 prod = w * (f2){h, h};
                             acc[r] = acc[r] + prod;
                         } else {
@@ -379,12 +407,12 @@ __device__ __forceinline__ void outx_step(const f2 *__restrict__ wl, const float
         }
 #pragma unroll
         for (int r = 0; r < kR; r++) asm volatile("" : "+v"(acc[r]));
-        outx_step<T, D, STEREO, G + 1>(wl, table, acc, hA, hB);
+        outx_step<T, D, STEREO, EXACT, G + 1>(wl, table, acc, hA, hB);
     }
 }
 
-template <int T, int D, bool STEREO>
-__global__ __launch_bounds__(64) void chs_out_exact_kernel(const float *__restrict__ demod, long dpitch, int Hd, const float *__restrict__ bpf,
+template <int T, int D, bool STEREO, bool EXACT>
+__global__ __launch_bounds__(64) void chs_out_kernel(const float *__restrict__ demod, long dpitch, int Hd, const float *__restrict__ bpf,
                                                             const float *__restrict__ nco, long ypitch, const float *__restrict__ nco0,
                                                             const float *__restrict__ mix_tail_in, float *__restrict__ mix_tail_out, int hm,
                                                             long n_if, long g_hi, int delay, const float *__restrict__ table,
@@ -407,7 +435,7 @@ __global__ __launch_bounds__(64) void chs_out_exact_kernel(const float *__restri
     const float first = STEREO ? nco0[c] : 0.0f;
     // D-1 samples past the window are visited too: when the block ends exactly on a tile boundary nobody's window reaches
     // the block's last D-1 samples, and they belong to the tail this call leaves behind
-    constexpr int NJ = (C::WL + D - 1 + 63) / 64, B = 7;
+    constexpr int NJ = (C::WL + D - 1 + 63) / 64, B = 14;         // 14 samples' three loads in flight per lane before the first use
     for (int q0 = 0; q0 < NJ; q0 += B) {
         float vm[B], va[B], vb[B];
 #pragma unroll
@@ -451,7 +479,7 @@ __global__ __launch_bounds__(64) void chs_out_exact_kernel(const float *__restri
     for (int r = 0; r < R; r++) acc[r] = (f2){0.0f, 0.0f};
     f16v hA, hB;
     CHS_TAPS_ISSUE(hA, table, 0);
-    outx_step<T, D, STEREO, 0>(win + (C::SEG + 1) * t, table, acc, hA, hB);
+    outx_step<T, D, STEREO, EXACT, 0>(win + (C::SEG + 1) * t, table, acc, hA, hB);
     const long k0 = a0 + static_cast<long>(t) * R;
     if (k0 >= a_hi) return;
     if constexpr (STEREO) {
@@ -535,6 +563,8 @@ struct StereoBank {
     long dpitch = 0, ypitch = 0;
     DevBuf<uint8_t> slots;
     DevBuf<float> fe_table, bpf_table, out_table;
+    FePlan fe;                      // fast banks: the matrix-core front end's tap image
+    Options opt;
     DevBuf<float> demod, carrier, bpf, trig, pll, nco0, mixtail[2];
     int mix_cur = 0;
     // A stereo call walks the block in chunks on two internal streams: `wide` carries the front end, the band-pass pair and the
@@ -544,10 +574,11 @@ struct StereoBank {
     static constexpr int kMaxChunks = 8;
     int max_chunks = kMaxChunks;
     hipStream_t wide = nullptr, lanes = nullptr;
-    hipEvent_t ev_bpf[kMaxChunks] = {}, ev_pll[kMaxChunks] = {}, ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t front = nullptr;    // fast banks: the HBM-bound front end runs on its own stream, next to the vector-ALU-bound kernels
+    hipEvent_t ev_bpf[kMaxChunks] = {}, ev_pll[kMaxChunks] = {}, ev_fe[kMaxChunks] = {}, ev_fork = nullptr, ev_join = nullptr;
     ~StereoBank()
     {
-        for (hipStream_t st : {wide, lanes})
+        for (hipStream_t st : {wide, lanes, front})
             if (st) {
                 (void)hipStreamSynchronize(st);
                 (void)hipStreamDestroy(st);
@@ -555,6 +586,8 @@ struct StereoBank {
         for (auto &e : ev_bpf)
             if (e) (void)hipEventDestroy(e);
         for (auto &e : ev_pll)
+            if (e) (void)hipEventDestroy(e);
+        for (auto &e : ev_fe)
             if (e) (void)hipEventDestroy(e);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
@@ -588,15 +621,16 @@ template <int T>
 int bpf_table_init(StereoBank &b, const float *h_st, const float *h_car)
 {
     using C = BpX<T>;
-    std::vector<float> tab(static_cast<size_t>(C::W) * 16, 0.0f);
-    for (int u = 0; u < C::W; u++)
-        for (int r = 0; r < kR; r++) {
-            const int n = r + (T - 1) - (C::W - 1 - u);
-            if (n >= 0 && n < T) {
-                tab[static_cast<size_t>(u) * 16 + 2 * r] = h_st[n];
-                tab[static_cast<size_t>(u) * 16 + 2 * r + 1] = h_car[n];
-            }
+    // P[m] = (h_st, h_car)[m - (R-1)], zero outside the filter, in groups of eight pairs; two groups of padding behind the last block
+    constexpr int NBLK = (C::W + 7) / 8;
+    std::vector<float> tab(static_cast<size_t>(NBLK + 2) * 16, 0.0f);
+    for (int m = 0; m < (NBLK + 2) * 8; m++) {
+        const int n = m - (kR - 1);
+        if (n >= 0 && n < T) {
+            tab[2 * static_cast<size_t>(m)] = h_st[n];
+            tab[2 * static_cast<size_t>(m) + 1] = h_car[n];
         }
+    }
     FMRX_TRY(b.bpf_table.alloc(tab.size()));
     FMRX_HIP(hipMemcpy(b.bpf_table.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
     return FMRX_OK;
@@ -624,9 +658,13 @@ template <int T>
 int launch_bpf(const StereoBank &b, long k_lo, long k_hi, hipStream_t s)
 {
     const long wgs = (k_hi - k_lo + 64 * kR - 1) / (64 * kR);
-    hipLaunchKernelGGL((chs_bpf_exact_kernel<T>), dim3(static_cast<unsigned>(wgs * b.n_channels)), dim3(64), 0, s, b.demod.p, b.dpitch,
-                       b.Hd, k_lo, k_hi, wgs, b.bpf_table.p, b.bpf.p, b.carrier.p, b.ypitch);
-    CHS_LAUNCH_CHECK("chs_bpf_exact_kernel");
+    if (b.exact)
+        hipLaunchKernelGGL((chs_bpf_kernel<T, true>), dim3(static_cast<unsigned>(wgs * b.n_channels)), dim3(64), 0, s, b.demod.p, b.dpitch,
+                           b.Hd, k_lo, k_hi, wgs, b.bpf_table.p, b.bpf.p, b.carrier.p, b.ypitch);
+    else
+        hipLaunchKernelGGL((chs_bpf_kernel<T, false>), dim3(static_cast<unsigned>(wgs * b.n_channels)), dim3(64), 0, s, b.demod.p, b.dpitch,
+                           b.Hd, k_lo, k_hi, wgs, b.bpf_table.p, b.bpf.p, b.carrier.p, b.ypitch);
+    CHS_LAUNCH_CHECK("chs_bpf_kernel");
     return FMRX_OK;
 }
 
@@ -638,19 +676,28 @@ int launch_out(StereoBank &b, float *d_audio, int16_t *d_pcm, int wrap, long a_l
     if ((reinterpret_cast<uintptr_t>(d_audio) % 16) || (reinterpret_cast<uintptr_t>(d_pcm) % 16) || (STEREO && b.n_audio % 4))
         return fail(FMRX_EINVAL, "channels: output buffers must be 16-byte aligned");
     const long wgs = (a_hi - a_lo + C::NOUT - 1) / C::NOUT;
-    hipLaunchKernelGGL((chs_out_exact_kernel<T, D, STEREO>), dim3(static_cast<unsigned>(wgs * b.n_channels)), dim3(64), 0, s, b.demod.p,
-                       b.dpitch, b.Hd, b.bpf.p, b.trig.p, b.ypitch, b.nco0.p, b.mixtail[b.mix_cur].p, b.mixtail[b.mix_cur ^ 1].p, b.Hm,
-                       b.n_if, g_hi, b.delay, b.out_table.p, wgs, d_audio, d_pcm, wrap, a_lo, a_hi, b.n_audio);
-    CHS_LAUNCH_CHECK("chs_out_exact_kernel");
+    if (b.exact)
+        hipLaunchKernelGGL((chs_out_kernel<T, D, STEREO, true>), dim3(static_cast<unsigned>(wgs * b.n_channels)), dim3(64), 0, s, b.demod.p,
+                           b.dpitch, b.Hd, b.bpf.p, b.trig.p, b.ypitch, b.nco0.p, b.mixtail[b.mix_cur].p, b.mixtail[b.mix_cur ^ 1].p, b.Hm,
+                           b.n_if, g_hi, b.delay, b.out_table.p, wgs, d_audio, d_pcm, wrap, a_lo, a_hi, b.n_audio);
+    else if constexpr (STEREO)
+        hipLaunchKernelGGL((chs_out_kernel<T, D, true, false>), dim3(static_cast<unsigned>(wgs * b.n_channels)), dim3(64), 0, s, b.demod.p,
+                           b.dpitch, b.Hd, b.bpf.p, b.trig.p, b.ypitch, b.nco0.p, b.mixtail[b.mix_cur].p, b.mixtail[b.mix_cur ^ 1].p, b.Hm,
+                           b.n_if, g_hi, b.delay, b.out_table.p, wgs, d_audio, d_pcm, wrap, a_lo, a_hi, b.n_audio);
+    CHS_LAUNCH_CHECK("chs_out_kernel");
     return FMRX_OK;
 }
 
 int launch_nco(const StereoBank &b, long k_lo, long k_hi, hipStream_t s)
 {
     const long wgs = (k_hi - k_lo + 1023) / 1024;
-    hipLaunchKernelGGL(chs_nco_exact_kernel, dim3(static_cast<unsigned>(wgs * b.n_channels)), dim3(256), 0, s, b.trig.p, b.ypitch, k_lo, k_hi, wgs,
-                       2.0f, 0.0f);
-    CHS_LAUNCH_CHECK("chs_nco_exact_kernel");
+    if (b.exact)
+        hipLaunchKernelGGL(chs_nco_kernel<true>, dim3(static_cast<unsigned>(wgs * b.n_channels)), dim3(256), 0, s, b.trig.p, b.ypitch, k_lo, k_hi,
+                           wgs, 2.0f, 0.0f);
+    else
+        hipLaunchKernelGGL(chs_nco_kernel<false>, dim3(static_cast<unsigned>(wgs * b.n_channels)), dim3(256), 0, s, b.trig.p, b.ypitch, k_lo, k_hi,
+                           wgs, 2.0f, 0.0f);
+    CHS_LAUNCH_CHECK("chs_nco_kernel");
     return FMRX_OK;
 }
 
@@ -688,8 +735,9 @@ bool stereo_bank_supported(const fmrx_params &p, int audio_channels)
 
 void stereo_bank_destroy(StereoBank *b) { delete b; }
 
-int stereo_bank_create(StereoBank **out, const fmrx_params &p, int n_channels, int audio_channels, size_t block_bytes)
+int stereo_bank_create(StereoBank **out, const fmrx_params &p, int n_channels, int audio_channels, int exact, size_t block_bytes)
 {
+    if (!exact && audio_channels != 2) return fail(FMRX_EINVAL, "channels: the fast mono bank is fmrx_channels_create's");
     if (!stereo_bank_supported(p, audio_channels))
         return fail(FMRX_EINVAL, "channels (exact): no reference-order kernels for rf %d/%d, audio %d/%d, stereo %d taps (modes 0 and 1 of the "
                     "reference's tap sets are covered)", p.rf_taps, p.rf_decim, p.audio_taps, p.audio_decim, p.stereo_taps);
@@ -697,6 +745,8 @@ int stereo_bank_create(StereoBank **out, const fmrx_params &p, int n_channels, i
     b->p = p;
     b->n_channels = n_channels;
     b->audio_channels = audio_channels;
+    b->exact = exact ? 1 : 0;
+    b->opt = options_snapshot();
     b->block_bytes = block_bytes;
     auto body = [&]() -> int {
         std::vector<float> h(p.rf_taps);
@@ -704,6 +754,13 @@ int stereo_bank_create(StereoBank **out, const fmrx_params &p, int n_channels, i
 #define X(T_, D_) if (p.rf_taps == T_ && p.rf_decim == D_) FMRX_TRY((fe_table_init<T_, D_>(*b, h.data())));
         CHS_FE_CASES(X)
 #undef X
+        if (!b->exact) {   // the matrix-core front end (int8 MFMA on the raw bytes): its tap image, and the history its windows reach
+            FMRX_TRY(fe_plan_init(b->fe, h.data(), p.rf_taps, p.rf_decim));
+            const int lead = fe_mfma_bank_lead(b->fe);
+            if (!b->fe.mfma || lead < 0) return fail(FMRX_EINVAL, "channels: no matrix-core front end for rf %d taps / decim %d", p.rf_taps, p.rf_decim);
+            const size_t need = (static_cast<size_t>(lead) + 15) / 16 * 16;
+            if (need > b->hist_bytes) b->hist_bytes = need;
+        }
         std::vector<float> ha(p.audio_taps);
         design_lpf(static_cast<float>(p.if_Fs), 16000.0f, p.audio_taps, ha.data());           // src/project.cpp:321
 #define X(T_, D_) if (p.audio_taps == T_ && p.audio_decim == D_) FMRX_TRY((out_table_init<T_, D_>(*b, ha.data())));
@@ -753,6 +810,8 @@ int stereo_bank_create(StereoBank **out, const fmrx_params &p, int n_channels, i
             CHS_LAUNCH_CHECK("chs_fill_state_kernel");
             FMRX_HIP(hipStreamCreateWithFlags(&b->wide, hipStreamNonBlocking));
             FMRX_HIP(hipStreamCreateWithFlags(&b->lanes, hipStreamNonBlocking));
+            FMRX_HIP(hipStreamCreateWithFlags(&b->front, hipStreamNonBlocking));
+            for (auto &e : b->ev_fe) FMRX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             for (auto &e : b->ev_bpf) FMRX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             for (auto &e : b->ev_pll) FMRX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             FMRX_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
@@ -806,6 +865,10 @@ int stereo_bank_process_dev(StereoBank *b, float *d_audio, int16_t *d_pcm, int w
 {
     const fmrx_params &p = b->p;
     auto fe = [&](long k_lo, long k_hi, hipStream_t st) -> int {
+        if (!b->exact)
+            return fe_mfma_bank_launch(b->fe, b->slots.p, static_cast<long>(b->slots.n), static_cast<long>(b->slot_bytes),
+                                       static_cast<long>(b->hist_bytes), b->n_channels, k_lo, k_hi, b->demod.p, b->dpitch, b->Hd,
+                                       b->opt.bank_fe_wgs, st);
 #define X(T_, D_) if (p.rf_taps == T_ && p.rf_decim == D_) return launch_fe<T_, D_>(*b, k_lo, k_hi, st);
         CHS_FE_CASES(X)
 #undef X
@@ -830,16 +893,25 @@ int stereo_bank_process_dev(StereoBank *b, float *d_audio, int16_t *d_pcm, int w
         per = (per + unit - 1) / unit * unit;
         const int K = static_cast<int>((b->n_audio + per - 1) / per);
         hipStream_t sw = K > 1 ? b->wide : s, sl = K > 1 ? b->lanes : s;
+        // fast banks: the front end is HBM-bound on the matrix cores, the band-pass pair and the output stage are bound by the
+        // vector ALUs: on two streams they run side by side (option bank_streams = 2: everything but the PLL on one stream)
+        const bool split = K > 1 && !b->exact && b->opt.bank_streams >= 3;
+        hipStream_t sf = split ? b->front : sw;
         if (K > 1) {   // whatever the caller's stream did before the call (loading the slots, reading the last output) comes first
             FMRX_HIP(hipEventRecord(b->ev_fork, s));
             FMRX_HIP(hipStreamWaitEvent(sw, b->ev_fork, 0));
             FMRX_HIP(hipStreamWaitEvent(sl, b->ev_fork, 0));
+            if (split) FMRX_HIP(hipStreamWaitEvent(sf, b->ev_fork, 0));
         }
         for (int c = 0; c <= K; c++) {
             if (c < K) {
                 const long a_lo = c * per, a_hi = a_lo + per < b->n_audio ? a_lo + per : b->n_audio;
                 const long k_lo = a_lo * p.audio_decim, k_hi = a_hi * p.audio_decim;
-                FMRX_TRY(fe(k_lo, k_hi, sw));
+                FMRX_TRY(fe(k_lo, k_hi, sf));
+                if (split) {   // read-after-write: the band-pass pair reads the discriminator rows the front end wrote on its own stream
+                    FMRX_HIP(hipEventRecord(b->ev_fe[c], sf));
+                    FMRX_HIP(hipStreamWaitEvent(sw, b->ev_fe[c], 0));
+                }
                 FMRX_TRY(bpf(k_lo, k_hi, sw));
                 if (K > 1) {
                     FMRX_HIP(hipEventRecord(b->ev_bpf[c], sw));
@@ -848,7 +920,7 @@ int stereo_bank_process_dev(StereoBank *b, float *d_audio, int16_t *d_pcm, int w
                 // fmPLL(carrier_filt, 19 kHz, if_Fs, ncoScale 2, phaseAdjust 0, normBandwidth 0.01): src/project.cpp:237
                 FMRX_TRY(k_fm_pll_channels(b->carrier.p + k_lo, b->ypitch, static_cast<size_t>(k_hi - k_lo), b->n_channels, b->trig.p + k_lo,
                                            b->ypitch, b->pll.p, c == 0 ? b->nco0.p : nullptr, 19e3f, static_cast<float>(p.if_Fs), 2.0f, 0.0f,
-                                           0.01f, sl));
+                                           0.01f, sl, true, b->exact != 0));
                 if (K > 1) FMRX_HIP(hipEventRecord(b->ev_pll[c], sl));
             }
             if (c > 0) {   // the output stage of the chunk before, behind this chunk's front end and band-pass pair on the wide stream

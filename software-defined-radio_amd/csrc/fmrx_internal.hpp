@@ -62,6 +62,10 @@ struct Options {
     int pll_head = -1;             // "pll_head" / FMRX_PLL_HEAD: samples of a stream's first call walked serially (-1 = built-in)
     int pll_mode = 0;              // "pll_mode" / FMRX_PLL_MODE: stereo PLL of the specialised pipeline: 0 = parallel in time, fast math
                                    //   (default); 1 = serial, fast math; 2 = serial, glibc math (the cause-by-cause variants of DESIGN 2)
+    int bank_streams = 3;          // "bank_streams" / FMRX_BANK_STREAMS: fast stereo banks: 3 = front end | band-pass pair + output stage | PLL lanes on
+                                   //   three internal streams (default), 2 = the front end on the same stream as the other wide kernels
+    int bank_fe_wgs = 1;           // "bank_fe_wgs" / FMRX_BANK_FE_WGS: workgroups per CU of the bank's matrix-core front end (1 leaves registers and
+                                   //   LDS for the kernels that run next to it; 0 = as many as fit)
     int demod = 0;                 // "demod" / FMRX_DEMOD: 0 = the C++ reference's discriminator (fmDemod, src/filter.cpp:248-266; default),
                                    //   1 = the Python model's arctangent demodulator (fmDemodArctan, model/fmSupportLib.py:502-531), float64
     int fused_tune = 0;            // "fused_tune", "fe_mfma_tune": ablation variants, honoured only by a -DFMRX_TUNING build
@@ -128,6 +132,10 @@ int fe_mfma_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, cons
                    float *d_demod, float *d_if, float *d_prev_out, uint8_t *d_hist_next, const Options &o, hipStream_t stream,
                    const float *d_dhist_src = nullptr, float *d_dhist_dst = nullptr, int dhist_n = 0);
 // (d_dhist_src -> d_dhist_dst, dhist_n floats: the discriminator history copied in front of this block's output by the kernel itself)
+// the same kernel over a bank of receivers' slots (channels_stereo.hip): see kernels_fe_mfma.hip
+int fe_mfma_bank_lead(const FePlan &pl);   // bytes of the stream a row needs in front of its block
+int fe_mfma_bank_launch(const FePlan &pl, const uint8_t *d_slots, long total_bytes, long in_pitch, long block_off, int n_channels,
+                        long k_lo, long k_hi, float *d_demod, long out_pitch, long out_off, int wgs_per_cu_cap, hipStream_t stream);
 // d_hist: hist_bytes bytes whose LAST 2*(taps-1) hold the previous samples.
 // Writes n_samples/decim float2 (I,Q) to d_if.
 int fe_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist, float *d_if,
@@ -276,7 +284,8 @@ size_t pll_parallel_lti_floats(size_t n);
 // many channels, lane = channel, the exact serial recurrence (kernels_pll.hip); rows [channel][pitch], state 8 floats per channel
 int k_fm_pll_channels(const float *d_in, long pitch_in, size_t n, int n_ch, float *d_trig, long pitch_trig, float *d_state,
                       float *d_nco0, float freq, float Fs, float ncoScale, float phaseAdjust, float normBandwidth, hipStream_t s,
-                      bool flat = true);   // flat: the branch-free forms of glibc's functions (same values; false = A/B)
+                      bool flat = true,    // flat: the branch-free forms of glibc's functions (same values; false = A/B)
+                      bool exact = true);  // false: the fast recurrence (closed-form phase detector, hardware sine / cosine) of the specialised path
 int k_mix(const float *d_bpf, const float *d_pll, size_t n, float *d_mix, hipStream_t s);
 int k_combine(const float *d_st, const float *d_mono, size_t n, float *d_l, float *d_r, hipStream_t s);
 int k_upsample(const float *d_x, size_t n, float *d_xu, int up, hipStream_t s);
@@ -295,7 +304,7 @@ int k_estimate_psd(const float *d_x, size_t n, float Fs, int nfft, float *d_seg_
 // ---- banks of receivers in the reference's evaluation order (channels_stereo.hip) ----
 struct StereoBank;
 bool stereo_bank_supported(const fmrx_params &p, int audio_channels);
-int stereo_bank_create(StereoBank **out, const fmrx_params &p, int n_channels, int audio_channels, size_t block_bytes);
+int stereo_bank_create(StereoBank **out, const fmrx_params &p, int n_channels, int audio_channels, int exact, size_t block_bytes);
 void stereo_bank_destroy(StereoBank *b);
 size_t stereo_bank_n_audio(const StereoBank *b);
 uint8_t *stereo_bank_first_block(const StereoBank *b);

@@ -375,6 +375,101 @@ int launch_mfma(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const u
     return FMRX_OK;
 }
 
+// ---- the same front end over a BANK of receivers (channels_stereo.hip) -------------------------------------------
+// One launch covers the IF outputs [out_off, out_off + n_row) of EVERY channel's block: tile tau = (channel tau / tiles_per_row,
+// tile tau % tiles_per_row of that channel's range).  Input rows are the bank's slots [history | block] (pitch in_pitch
+// bytes; the history in front of a block holds the stream's last bytes, so every window is read from one contiguous
+// row and no tile is special), output rows the bank's discriminator rows.  Same arithmetic as fe_mfma_kernel's general
+// loop (same integers: IF samples are bit-identical to the single-stream kernels'); no IF output, no carried IF sample (column 0
+// of a row's first tile recomputes it from the history like any other).  n_row is even (host contract): every tile issues
+// exactly one f2 store, which the counted waits rely on.
+struct FeBankGeom {
+    long in_pitch, in_off;     // bytes between channels' slots; byte offset of output 0's first sample inside a slot
+    long out_pitch, out_off;   // floats between channels' rows; offset of output 0 inside a row
+    long n_row;                // outputs per channel in this launch
+    int tiles_per_row;
+};
+
+template <int T, int D>
+__global__ __launch_bounds__(256, 2) void fe_mfma_bank_kernel(const uint8_t *__restrict__ x, long n_bytes, const i4 *__restrict__ a_img,
+                                                               float scale_lo, float *__restrict__ demod, FeBankGeom bk, int n_tiles)
+{
+    using C = MfCfg<T, D, 0>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    uint8_t *ring = lds_raw + wave * C::RING;
+    const int tstep = static_cast<int>(gridDim.x) * 4;
+    int tile = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * 4 + wave);
+    if (tile >= n_tiles) return;
+    i4 a[C::KSTEPS][C::NDIG];
+#pragma unroll
+    for (int j = 0; j < C::KSTEPS; j++)
+#pragma unroll
+        for (int d = 0; d < C::NDIG; d++) a[j][d] = a_img[(j * C::NDIG + d) * 64 + lane];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < C::KSTEPS; j++)
+#pragma unroll
+        for (int d = 0; d < C::NDIG; d++) asm volatile("" : "+v"(a[j][d]));
+    auto dma = [&](int t, int rs) {
+        const int c = t / bk.tiles_per_row, j = t - c * bk.tiles_per_row;
+        const long s0 = c * bk.in_pitch + bk.in_off + static_cast<long>(j) * C::STRIDE_BYTES - C::LEAD;
+        dma_window<C::NPF, C::REM_LANES, 0>(x, x, n_bytes, s0, ring + rs * C::SLOT, lane);
+    };
+#pragma unroll
+    for (int k = 0; k < C::P; k++)
+        if (tile + k * tstep < n_tiles) dma(tile + k * tstep, k);
+    const int col = lane & 15, g = lane >> 4;
+    const int lane_off = C::COL_BYTES * col + 16 * g;
+    const float scale_hi = scale_lo * 65536.0f;
+    const int src_lane = lane >= 16 ? lane - 16 : lane + 47;
+    int slot = 0, fill = C::P;
+    for (int it = 0; tile < n_tiles; tile += tstep, it++) {
+        const bool steady = tile + C::P * tstep < n_tiles;
+        if (steady) dma(tile + C::P * tstep, fill);
+        if (steady) {
+            if (it < C::P) wait_vmcnt<C::YOUNGER>();
+            else wait_vmcnt<C::YOUNGER + C::P>();
+        } else {
+            wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint8_t *bsrc = ring + slot * C::SLOT + lane_off;
+        i4 b[C::KSTEPS];
+#pragma unroll
+        for (int j = 0; j < C::KSTEPS; j++) b[j] = *reinterpret_cast<const i4 *>(bsrc + 64 * j);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        i4 acc[C::NDIG];
+#pragma unroll
+        for (int d = 0; d < C::NDIG; d++) acc[d] = (i4){0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < C::KSTEPS; j++) {
+            const i4 bs = b[j] ^ static_cast<int>(0x80808080u);
+#pragma unroll
+            for (int d = 0; d < C::NDIG; d++) acc[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[j][d], bs, acc[d], 0, 0, 0);
+        }
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int lo = acc[0][k];
+            if (C::NDIG >= 2) lo += acc[1][k] * 256;
+            const float flo = static_cast<float>(lo) * scale_lo;
+            v[k] = C::NDIG >= 3 ? __builtin_fmaf(static_cast<float>(acc[2][k]), scale_hi, flo) : flo;
+        }
+        const float pi = __shfl(v[2], src_lane, 64), pq = __shfl(v[3], src_lane, 64);
+        const float d0 = demod_fast(v[0], v[1], pi, pq), d1 = demod_fast(v[2], v[3], v[0], v[1]);
+        const int c = tile / bk.tiles_per_row, j = tile - c * bk.tiles_per_row;
+        const long ol = static_cast<long>(j) * C::TILE_OUT + C::COL_OUT * (col - 1) + 2 * g;   // output inside this launch's range of the row
+        if (col > 0 && ol < bk.n_row) *reinterpret_cast<f2 *>(demod + c * bk.out_pitch + bk.out_off + ol) = (f2){d0, d1};
+        slot = slot + 1 == C::NSLOT ? 0 : slot + 1;
+        fill = fill + 1 == C::NSLOT ? 0 : fill + 1;
+    }
+}
+
 // ============================================================================================
 // Fused mono chain: RF_FrontEnd + RF_MONO of modes 0/1 (src/project.cpp:82-128, 330-350;
 // src/threadMonoOnly.cpp:185-191) in ONE kernel: u8 I/Q in, float audio and/or s16 PCM out.  The
@@ -992,6 +1087,29 @@ int fe_mfma_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, cons
     FMRX_FE_MFMA_CASES(X)
 #undef X
     return fail(FMRX_EINVAL, "fe_mfma_launch: no kernel for taps=%d decim=%d", pl.taps, pl.decim);
+}
+
+int fe_mfma_bank_lead(const FePlan &pl)
+{
+#define X(T_, D_) if (pl.taps == T_ && pl.decim == D_) return MfCfg<T_, D_>::LEAD;
+    FMRX_FE_MFMA_CASES(X)
+#undef X
+    return -1;
+}
+
+// d_slots: n_channels rows of in_pitch bytes; the IF outputs [k_lo, k_hi) of every row's block (which starts block_off bytes into the
+// row, with >= fe_mfma_bank_lead() bytes of the stream in front of it) -> d_demod + c * out_pitch + out_off + k.  total_bytes: size of
+// the slots buffer (reads are clamped to it).  wgs_per_cu: cap on resident workgroups per CU (0 = as many as fit).
+int fe_mfma_bank_launch(const FePlan &pl, const uint8_t *d_slots, long total_bytes, long in_pitch, long block_off, int n_channels,
+                        long k_lo, long k_hi, float *d_demod, long out_pitch, long out_off, int wgs_per_cu_cap, hipStream_t stream)
+{
+    if (!pl.mfma) return fail(FMRX_EINVAL, "fe_mfma_bank: no matrix-core kernel for taps=%d decim=%d", pl.taps, pl.decim);
+    if ((k_hi - k_lo) % 2 || (k_lo * pl.decim * 2) % 16 || in_pitch % 16 || block_off % 16 || out_pitch % 2 || (out_off + k_lo) % 2)
+        return fail(FMRX_EINVAL, "fe_mfma_bank: misaligned geometry");
+#define X(T_, D_)                                                                                                            if (pl.taps == T_ && pl.decim == D_) {                                                                                       using C = MfCfg<T_, D_>;                                                                                                 FeBankGeom bk;                                                                                                           bk.in_pitch = in_pitch;                                                                                                  bk.in_off = block_off + k_lo * D_ * 2;                                                                                   bk.out_pitch = out_pitch;                                                                                                bk.out_off = out_off + k_lo;                                                                                             bk.n_row = k_hi - k_lo;                                                                                                  bk.tiles_per_row = static_cast<int>((bk.n_row + C::TILE_OUT - 1) / C::TILE_OUT);                                          const long n_tiles = static_cast<long>(bk.tiles_per_row) * n_channels;                                                   if (n_tiles > 0x7fffffffL / 4) return fail(FMRX_EINVAL, "fe_mfma_bank: too many tiles");                                  long wgs_per_cu = (160 * 1024) / (4L * C::RING);                                                                         if (wgs_per_cu > 2) wgs_per_cu = 2;                                                                                      if (wgs_per_cu_cap >= 1 && wgs_per_cu_cap < wgs_per_cu) wgs_per_cu = wgs_per_cu_cap;                                     const long want = (n_tiles + 3) / 4;                                                                                     const long grid = want < 256 * wgs_per_cu ? want : 256 * wgs_per_cu;                                                     hipLaunchKernelGGL((fe_mfma_bank_kernel<T_, D_>), dim3(static_cast<unsigned>(grid)), dim3(256), 4 * C::RING, stream, d_slots,                            total_bytes, reinterpret_cast<const i4 *>(pl.a_img.p), pl.scale_lo, d_demod, bk, static_cast<int>(n_tiles));         hipError_t e = hipGetLastError();                                                                                        if (e != hipSuccess) return fail(FMRX_EHIP, "launch fe_mfma_bank_kernel<%d,%d>: %s", T_, D_, hipGetErrorString(e));         return FMRX_OK;                                                                                                      }
+    FMRX_FE_MFMA_CASES(X)
+#undef X
+    return fail(FMRX_EINVAL, "fe_mfma_bank: no kernel for taps=%d decim=%d", pl.taps, pl.decim);
 }
 
 // Toeplitz image of the audio taps in A-operand order of v_mfma_f32_16x16x4_f32: [kstep][lane], lane

@@ -696,14 +696,20 @@ __global__ __launch_bounds__(kRepairThreads) void pll_repair_kernel(
 // Rows are 16-byte aligned with >= 16 readable floats behind their n samples (host contract): the input is fetched as
 // 16-byte groups three groups ahead of the chain.
 template <int MATH, bool FLAT>
-__global__ __launch_bounds__(64) void pll_channels_kernel(const float *__restrict__ in, long pitch_in, long n, long n_ch,
+__global__ __launch_bounds__(64, 1) void pll_channels_kernel(const float *__restrict__ in, long pitch_in, long n, long n_ch,
                                                            float *__restrict__ trig, long pitch_trig, float *__restrict__ state,
                                                            float *__restrict__ nco0, PllCoef c)
 {
     typedef float f4 __attribute__((ext_vector_type(4)));
+    constexpr int kBatch = 32;                                 // samples per lane and batch = one 128-byte line of its row
     __shared__ uint32_t w24[24];
+    __shared__ float lin[kBatch * 64], lout[kBatch * 64];      // [sample][lane]: every lane reads and writes its own column
     if (threadIdx.x < 24) w24[threadIdx.x] = glibc235::inv_pio4(threadIdx.x);
     __syncthreads();
+    // These waves are a dependent chain each and run next to wide kernels that fill every other issue slot of their SIMD: the
+    // highest wave priority gives the chain every slot it can use (it can use few).
+    __builtin_amdgcn_s_setprio(3);
+    const int lane = threadIdx.x;
     const long ch = static_cast<long>(blockIdx.x) * 64 + threadIdx.x;
     if (ch >= n_ch) return;
     float *st = state + 8 * ch;
@@ -712,15 +718,24 @@ __global__ __launch_bounds__(64) void pll_channels_kernel(const float *__restric
     if (nco0) nco0[ch] = s.last;
     const f4 *in4 = reinterpret_cast<const f4 *>(in + ch * pitch_in);
     f4 *out4 = reinterpret_cast<f4 *>(trig + ch * pitch_trig);
-    const long ng = n / 4;
-    f4 q0 = in4[0], q1 = in4[1], q2 = in4[2];
-    for (long g = 0; g < ng; g++) {
-        const f4 cur = q0;
-        q0 = q1;
-        q1 = q2;
-        q2 = in4[g + 3];
+    // four steps of the recurrence: the samples in, the raw trigArg of each step out
+    auto four = [&](const f4 cur) __attribute__((always_inline)) -> f4 {   // (called twice: outlined, the state would live in scratch)
         f4 r;
-        if (MATH == kExact && FLAT) {
+        if (MATH == kFast) {
+            // the specialised path's step (closed-form phase detector, one double argument reduction); one wave-uniform test
+            // per group sends the whole wave through the general fast step when any lane meets a zero / non-finite sample
+            if (__builtin_expect(__any(!(pll_ordinary(cur.x) && pll_ordinary(cur.y) && pll_ordinary(cur.z) && pll_ordinary(cur.w))), 0)) {
+                pll_step<kFast>(s, cur.x, c); r.x = s.last;
+                pll_step<kFast>(s, cur.y, c); r.y = s.last;
+                pll_step<kFast>(s, cur.z, c); r.z = s.last;
+                pll_step<kFast>(s, cur.w, c); r.w = s.last;
+            } else {
+                pll_step_clean(s, cur.x, c); r.x = s.last;
+                pll_step_clean(s, cur.y, c); r.y = s.last;
+                pll_step_clean(s, cur.z, c); r.z = s.last;
+                pll_step_clean(s, cur.w, c); r.w = s.last;
+            }
+        } else if (MATH == kExact && FLAT) {
             pll_step_exact_flat(s, cur.x, c, w24); r.x = s.last;
             pll_step_exact_flat(s, cur.y, c, w24); r.y = s.last;
             pll_step_exact_flat(s, cur.z, c, w24); r.z = s.last;
@@ -731,10 +746,61 @@ __global__ __launch_bounds__(64) void pll_channels_kernel(const float *__restric
             pll_step<MATH>(s, cur.z, c); r.z = s.last;
             pll_step<MATH>(s, cur.w, c); r.w = s.last;
         }
-        out4[g] = r;
+        return r;
+    };
+    // Whole batches.  The recurrence must never wait for memory: a batch's input is requested a whole batch (3-15 us of chain)
+    // before it is used, passes through registers into LDS, and the inner loop touches LDS only; the batch's output leaves
+    // from LDS behind the next requests.  (The compiler waits for ALL outstanding global accesses where it needs one of them:
+    // with loads and stores inside the loop of steps every group of four steps paid a memory round trip.)
+    const long nb = n / kBatch;
+    f4 pre[kBatch / 4];
+    if (nb > 0) {
+#pragma unroll
+        for (int g = 0; g < kBatch / 4; g++) pre[g] = in4[g];
     }
-    for (long k = 4 * ng, i = 0; k < n; k++, i++) {          // a block that is not a multiple of four samples
-        pll_step<MATH>(s, q0[i], c);
+    for (long b = 0; b < nb; b++) {
+        // (1) this batch's input -> LDS (requested a batch ago); (2) request the next batch
+#pragma unroll
+        for (int g = 0; g < kBatch / 4; g++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) lin[(4 * g + e) * 64 + lane] = pre[g][e];
+        if (b + 1 < nb) {
+#pragma unroll
+            for (int g = 0; g < kBatch / 4; g++) pre[g] = in4[(b + 1) * (kBatch / 4) + g];
+        }
+        // (3) the previous batch's output -> memory (its stores have this whole batch to complete)
+        if (b > 0) {
+#pragma unroll
+            for (int g = 0; g < kBatch / 4; g++)
+                out4[(b - 1) * (kBatch / 4) + g] = (f4){lout[(4 * g) * 64 + lane], lout[(4 * g + 1) * 64 + lane], lout[(4 * g + 2) * 64 + lane],
+                                                        lout[(4 * g + 3) * 64 + lane]};
+        }
+        // (4) the chain: LDS in, LDS out
+        f4 cur = (f4){lin[lane], lin[64 + lane], lin[128 + lane], lin[192 + lane]};
+#pragma unroll 1
+        for (int g = 0; g < kBatch / 4; g++) {
+            const int gn = g + 1 < kBatch / 4 ? g + 1 : g;
+            const f4 nxt = (f4){lin[(4 * gn) * 64 + lane], lin[(4 * gn + 1) * 64 + lane], lin[(4 * gn + 2) * 64 + lane],
+                                lin[(4 * gn + 3) * 64 + lane]};
+            const f4 r = four(cur);
+            lout[(4 * g) * 64 + lane] = r.x;
+            lout[(4 * g + 1) * 64 + lane] = r.y;
+            lout[(4 * g + 2) * 64 + lane] = r.z;
+            lout[(4 * g + 3) * 64 + lane] = r.w;
+            cur = nxt;
+        }
+    }
+    if (nb > 0) {
+#pragma unroll
+        for (int g = 0; g < kBatch / 4; g++)
+            out4[(nb - 1) * (kBatch / 4) + g] = (f4){lout[(4 * g) * 64 + lane], lout[(4 * g + 1) * 64 + lane], lout[(4 * g + 2) * 64 + lane],
+                                                     lout[(4 * g + 3) * 64 + lane]};
+    }
+    // what is left of a block that is not a multiple of the batch: groups of four, then single samples
+    long k = nb * kBatch;
+    for (; k + 4 <= n; k += 4) out4[k / 4] = four(in4[k / 4]);
+    for (; k < n; k++) {
+        pll_step<MATH>(s, in[ch * pitch_in + k], c);
         trig[ch * pitch_trig + k] = s.last;
     }
     finish_state<MATH>(s, c);
@@ -811,14 +877,18 @@ int k_fm_pll(const float *d_in, size_t n, float *d_out, float *d_state, float fr
 }
 
 int k_fm_pll_channels(const float *d_in, long pitch_in, size_t n, int n_ch, float *d_trig, long pitch_trig, float *d_state,
-                      float *d_nco0, float freq, float Fs, float ncoScale, float phaseAdjust, float normBandwidth, hipStream_t s, bool flat)
+                      float *d_nco0, float freq, float Fs, float ncoScale, float phaseAdjust, float normBandwidth, hipStream_t s, bool flat,
+                      bool exact)
 {
     if (n == 0 || n_ch <= 0) return FMRX_OK;
     if (reinterpret_cast<uintptr_t>(d_in) % 16 || reinterpret_cast<uintptr_t>(d_trig) % 16 || pitch_in % 4 || pitch_trig % 4 ||
         pitch_in < static_cast<long>(n) + 16)
         return fail(FMRX_EINVAL, "fm_pll_channels: rows must be 16-byte aligned with 16 readable floats behind their samples");
     const PllCoef c = make_coef(freq, Fs, ncoScale, phaseAdjust, normBandwidth);
-    if (flat)
+    if (!exact)
+        hipLaunchKernelGGL((pll_channels_kernel<kFast, false>), dim3(static_cast<unsigned>((n_ch + 63) / 64)), dim3(64), 0, s, d_in, pitch_in,
+                           static_cast<long>(n), static_cast<long>(n_ch), d_trig, pitch_trig, d_state, d_nco0, c);
+    else if (flat)
         hipLaunchKernelGGL((pll_channels_kernel<kExact, true>), dim3(static_cast<unsigned>((n_ch + 63) / 64)), dim3(64), 0, s, d_in, pitch_in,
                            static_cast<long>(n), static_cast<long>(n_ch), d_trig, pitch_trig, d_state, d_nco0, c);
     else

@@ -102,8 +102,44 @@ def test_bank_other_block_sizes(fmrx, oracle):
         fmrx.Channels(0, 4, audio_channels=2, exact=True, block_bytes=1600)      # shorter than the history a channel carries
     with pytest.raises(fmrx.FmrxError):
         fmrx.Channels(2, 4, audio_channels=2, exact=True)                        # resampling modes: not in the bank
-    with pytest.raises(fmrx.FmrxError):
-        fmrx.Channels(0, 4, audio_channels=2, exact=False)                       # stereo banks are exact
+
+
+def test_stereo_bank_fast_error_envelope(fmrx, oracle):
+    """The FAST stereo bank (exact = 0: matrix-core front end, one fma per tap in the band-pass pair and the audio FIRs, the
+    PLL's fast recurrence walked by one lane per channel) promises what the default single-stream path promises
+    (tests/test_gpu_parity.py: ENVELOPE_FACTOR): per channel and 0.1 s window, audio RMS error <= max(1e-4, 0.06
+    ulp(trigArg(t))) against the oracle, <= 1e-4 in the first window, mono sum (L+R)/2 <= 2e-6 throughout -- checked for
+    each of 24 receivers with distinct signals over 2.13 s, one call per reference block."""
+    from test_gpu_parity import ENVELOPE_FACTOR, stereo_error_envelope, trig_arg_ulp
+    p = oracle.mode_params(0, 101, 101, 101)
+    N, nblk, bb = 24, 100, p.block_bytes
+    with ProcessPoolExecutor(max_workers=min(12, os.cpu_count() or 1)) as ex:
+        res = sorted(ex.map(_oracle_channel, [(c, nblk, bb, float(p.rf_Fs)) for c in range(N)], chunksize=2), key=lambda r: r[0])
+    ch = fmrx.Channels(0, N, audio_channels=2, exact=False)
+    L = np.zeros((N, nblk * 1024), np.float32)
+    R = np.zeros((N, nblk * 1024), np.float32)
+    for b in range(nblk):
+        out = ch.process(np.stack([r[1][b * bb:(b + 1) * bb] for r in res]), want_pcm=(b == 0))
+        L[:, b * 1024:(b + 1) * 1024] = out["audio_l"]
+        R[:, b * 1024:(b + 1) * 1024] = out["audio_r"]
+        if b == 0:
+            # the s16 output is the pack of the float output (what is compared with the reference below)
+            for c in range(N):
+                bits_equal(out["pcm16"][c, :, 0], oracle.pcm16(out["audio_l"][c]), f"pcm left, channel {c}")
+                bits_equal(out["pcm16"][c, :, 1], oracle.pcm16(out["audio_r"][c]), f"pcm right, channel {c}")
+    win = 4800
+    t_end = (np.arange(nblk * 1024 // win) + 1) * 0.1
+    bound = np.maximum(1e-4, ENVELOPE_FACTOR * trig_arg_ulp(t_end))
+    worst = 0.0
+    for c in range(N):
+        for got, want in ((L[c], res[c][2]), (R[c], res[c][3])):
+            env = stereo_error_envelope(got, want, win)
+            assert (env <= bound).all(), (c, env, bound)
+            assert env[0] <= 1e-4
+            worst = max(worst, float((env / trig_arg_ulp(t_end)).max()))
+        mono = stereo_error_envelope((L[c].astype(np.float64) + R[c]) / 2, (res[c][2].astype(np.float64) + res[c][3]) / 2, win)
+        assert mono.max() <= 2e-6, (c, mono.max())
+    print(f"fast stereo bank: worst window error over {N} channels = {worst:.3f} ulp(trigArg)")
 
 
 def _oracle_channel(args):

@@ -15,12 +15,16 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--channels", default="1024,4096,16384")
 ap.add_argument("--audio-channels", type=int, default=2)
 ap.add_argument("--exact", type=int, default=1)
+ap.add_argument("--option", action="append", default=[], help="name=value library option (fmrx_set_option)")
 ap.add_argument("--mode", type=int, default=0)
 ap.add_argument("--blocks-per-call", type=int, default=1, help="reference-size blocks per channel and call")
 ap.add_argument("--calls", type=int, default=5)
 ap.add_argument("--distinct", type=int, default=64, help="distinct signals dealt round-robin over the channels")
 a = ap.parse_args()
 
+for kv in a.option:
+    k, v = kv.split("=")
+    fmrx.set_option(k, int(v))
 p = fmrx.modeParams(a.mode)
 bb = p.block_bytes * a.blocks_per_call
 ns = bb // 2
