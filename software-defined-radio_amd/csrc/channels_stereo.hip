@@ -152,8 +152,9 @@ __global__ __launch_bounds__(64) void chs_fe_exact_kernel(const uint8_t *__restr
     const long w0 = k0 * D - (T - 1) - C::LEAD;                  // first sample of the 16-byte aligned window
     const u4 *src = reinterpret_cast<const u4 *>(blk + 2 * w0);
     uint32_t raw[C::NB * 4];
+    // requested newest chunk first: that is the order the steps consume them in, so the arithmetic starts when the first load is back
 #pragma unroll
-    for (int i = 0; i < C::NB; i++) {
+    for (int i = C::NB - 1; i >= 0; i--) {
         const u4 v = src[i] ^ 0x80808080u;
         raw[4 * i] = v.x;
         raw[4 * i + 1] = v.y;
@@ -253,7 +254,8 @@ __device__ __forceinline__ void bpx_block(const float (&w)[BpX<T>::NW], const fl
 template <int T, bool EXACT>
 __global__ __launch_bounds__(64) void chs_bpf_kernel(const float *__restrict__ demod, long dpitch, int Hd, long k_lo, long n_if,
                                                              long wgs_per_channel, const float *__restrict__ table,
-                                                             float *__restrict__ y_st, float *__restrict__ y_car, long ypitch)
+                                                             float *__restrict__ y_st, float *__restrict__ y_car, long ypitch,
+                                                             int8_t *__restrict__ y_car8, long cpitch)
 {
     using C = BpX<T>;
     constexpr int R = kR;
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(64) void chs_bpf_kernel(const float *__restrict__ d
     const f4 *src = reinterpret_cast<const f4 *>(x + k0 - (T - 1) - C::LEAD);
     float w[C::NW];
 #pragma unroll
-    for (int i = 0; i < C::NW / 4; i++) {
+    for (int i = C::NW / 4 - 1; i >= 0; i--) {                  // newest chunk first: the order the steps consume them in
         const f4 v = src[i];
         w[4 * i] = v.x;
         w[4 * i + 1] = v.y;
@@ -278,19 +280,47 @@ __global__ __launch_bounds__(64) void chs_bpf_kernel(const float *__restrict__ d
     CHS_TAPS_ISSUE(g0, table, 0);
     CHS_TAPS_ISSUE(g1, table, 64);
     bpx_block<T, EXACT, 0>(w, table, acc, g0, g1, g2);
-    float *ds = y_st + c * ypitch + k0, *dc = y_car + c * ypitch + k0;
-    if (k0 + R <= n_if) {
-        reinterpret_cast<f4 *>(ds)[0] = (f4){acc[0].x, acc[1].x, acc[2].x, acc[3].x};
-        reinterpret_cast<f4 *>(ds)[1] = (f4){acc[4].x, acc[5].x, acc[6].x, acc[7].x};
-        reinterpret_cast<f4 *>(dc)[0] = (f4){acc[0].y, acc[1].y, acc[2].y, acc[3].y};
-        reinterpret_cast<f4 *>(dc)[1] = (f4){acc[4].y, acc[5].y, acc[6].y, acc[7].y};
-    } else {
+    float *ds = y_st + c * ypitch + k0;
+    if constexpr (!EXACT) {
+        // fast bank: the pilot band-pass output only feeds the PLL's fast recurrence, which reads its SIGN: one signed byte per sample
+        // (+1 / -1; 0 = not an ordinary sample: zero, denormal-small or not finite -- kernels_pll.hip: pll_ordinary)
+        uint32_t lo = 0, hi = 0;
 #pragma unroll
-        for (int r = 0; r < R; r++)
-            if (k0 + r < n_if) {
-                ds[r] = acc[r].x;
-                dc[r] = acc[r].y;
-            }
+        for (int r = 0; r < R; r++) {
+            const float v = acc[r].y;
+            const bool ord = fabsf(v) > 1e-20f && fabsf(v) < 1e20f;
+            const uint32_t code = ord ? (v > 0.0f ? 0x01u : 0xffu) : 0u;
+            if (r < 4) lo |= code << (8 * r);
+            else hi |= code << (8 * (r - 4));
+        }
+        int8_t *dc8 = y_car8 + c * cpitch + k0;
+        if (k0 + R <= n_if) {
+            reinterpret_cast<f4 *>(ds)[0] = (f4){acc[0].x, acc[1].x, acc[2].x, acc[3].x};
+            reinterpret_cast<f4 *>(ds)[1] = (f4){acc[4].x, acc[5].x, acc[6].x, acc[7].x};
+            *reinterpret_cast<uint2 *>(dc8) = make_uint2(lo, hi);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                if (k0 + r < n_if) {
+                    ds[r] = acc[r].x;
+                    dc8[r] = static_cast<int8_t>(((r < 4 ? lo : hi) >> (8 * (r % 4))) & 0xff);
+                }
+        }
+    } else {
+        float *dc = y_car + c * ypitch + k0;
+        if (k0 + R <= n_if) {
+            reinterpret_cast<f4 *>(ds)[0] = (f4){acc[0].x, acc[1].x, acc[2].x, acc[3].x};
+            reinterpret_cast<f4 *>(ds)[1] = (f4){acc[4].x, acc[5].x, acc[6].x, acc[7].x};
+            reinterpret_cast<f4 *>(dc)[0] = (f4){acc[0].y, acc[1].y, acc[2].y, acc[3].y};
+            reinterpret_cast<f4 *>(dc)[1] = (f4){acc[4].y, acc[5].y, acc[6].y, acc[7].y};
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                if (k0 + r < n_if) {
+                    ds[r] = acc[r].x;
+                    dc[r] = acc[r].y;
+                }
+        }
     }
 }
 
@@ -415,9 +445,9 @@ template <int T, int D, bool STEREO, bool EXACT>
 __global__ __launch_bounds__(64) void chs_out_kernel(const float *__restrict__ demod, long dpitch, int Hd, const float *__restrict__ bpf,
                                                             const float *__restrict__ nco, long ypitch, const float *__restrict__ nco0,
                                                             const float *__restrict__ mix_tail_in, float *__restrict__ mix_tail_out, int hm,
-                                                            long n_if, long g_hi, int delay, const float *__restrict__ table,
-                                                            long wgs_per_channel, float *__restrict__ audio, int16_t *__restrict__ pcm,
-                                                            int wrap, long a_lo, long a_hi, long n_out)
+                                                            long n_if, long g_hi, int delay, float nco_scale, float phase_adjust,
+                                                            const float *__restrict__ table, long wgs_per_channel, float *__restrict__ audio,
+                                                            int16_t *__restrict__ pcm, int wrap, long a_lo, long a_hi, long n_out)
 {
     using C = OutX<T, D>;
     constexpr int R = kR;
@@ -435,38 +465,52 @@ __global__ __launch_bounds__(64) void chs_out_kernel(const float *__restrict__ d
     const float first = STEREO ? nco0[c] : 0.0f;
     // D-1 samples past the window are visited too: when the block ends exactly on a tile boundary nobody's window reaches
     // the block's last D-1 samples, and they belong to the tail this call leaves behind
-    constexpr int NJ = (C::WL + D - 1 + 63) / 64, B = 14;         // 14 samples' three loads in flight per lane before the first use
-    for (int q0 = 0; q0 < NJ; q0 += B) {
-        float vm[B], va[B], vb[B];
-#pragma unroll
-        for (int q = 0; q < B; q++) {                          // a batch's loads in flight before the first use
-            const int j = t + (q0 + q) * 64;
-            const long g = g0 + j;
-            vm[q] = 0.0f;
-            va[q] = 0.0f;
-            vb[q] = first;                                     // PLL[0] = the incoming state's lastOut
-            if (j < C::WL + D - 1 && g < g_hi) {
-                vm[q] = dm[g - delay];                         // history in front of the row: negative indices are valid
-                if (STEREO) {
-                    va[q] = g >= 0 ? bp[g] : tin[hm + g];
-                    if (g > 0) vb[q] = nc[g - 1];              // PLL[g], finished by chs_nco_exact_kernel
-                }
-            }
-        }
+    // Staging in batches of B samples per lane, the next batch's three loads per sample in flight while this one is turned into
+    // LDS pairs.  EXACT: `nco` holds finished NCO values (chs_nco_kernel); fast bank: the raw trigArg of the PLL's steps, and the
+    // cosine is taken here (one argument reduction in double + the hardware cosine, kernels_pll.hip: nco_out<kFast>).
+    constexpr int NJ = (C::WL + D - 1 + 63) / 64, B = 11, NBATCH = (NJ + B - 1) / B;
+    float vm[2][B], va[2][B], vb[2][B];
+    auto fetch = [&](int q0, float (&m)[B], float (&a)[B], float (&b)[B]) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < B; q++) {
             const int j = t + (q0 + q) * 64;
             const long g = g0 + j;
+            m[q] = 0.0f;
+            a[q] = 0.0f;
+            b[q] = 0.0f;
+            if (j < C::WL + D - 1 && g < g_hi) {
+                m[q] = dm[g - delay];                          // history in front of the row: negative indices are valid
+                if (STEREO) {
+                    a[q] = g >= 0 ? bp[g] : tin[hm + g];
+                    if (g > 0) b[q] = nc[g - 1];               // PLL[g] = cos(trigArg[g-1] * ncoScale + phaseAdjust)
+                }
+            }
+        }
+    };
+    fetch(0, vm[0], va[0], vb[0]);
+#pragma unroll
+    for (int bi = 0; bi < NBATCH; bi++) {
+        if (bi + 1 < NBATCH) fetch((bi + 1) * B, vm[(bi + 1) & 1], va[(bi + 1) & 1], vb[(bi + 1) & 1]);
+#pragma unroll
+        for (int q = 0; q < B; q++) {
+            const int j = t + (bi * B + q) * 64;
+            const long g = g0 + j;
             if (j >= C::WL + D - 1) continue;
             float m = 0.0f, x = 0.0f;
             if (g < g_hi) {
-                m = vm[q];
+                m = vm[bi & 1][q];
                 if (STEREO) {
                     if (g >= 0) {
-                        x = (va[q] * vb[q]) * 2.0f;            // the reference's order: (stereo_filt * PLL) * 2
+                        float pll = vb[bi & 1][q];
+                        if (!EXACT) {
+                            const double rev = static_cast<double>(pll * nco_scale + phase_adjust) * 0.15915494309189533577;
+                            pll = __builtin_amdgcn_cosf(static_cast<float>(rev - rint(rev)));
+                        }
+                        if (g == 0) pll = first;               // PLL[0] = the incoming state's lastOut
+                        x = (va[bi & 1][q] * pll) * 2.0f;      // the reference's order: (stereo_filt * PLL) * 2
                         if (g >= n_if - hm) tout[g - (n_if - hm)] = x;
                     } else {
-                        x = va[q];
+                        x = va[bi & 1][q];
                     }
                 }
             }
@@ -566,6 +610,8 @@ struct StereoBank {
     FePlan fe;                      // fast banks: the matrix-core front end's tap image
     Options opt;
     DevBuf<float> demod, carrier, bpf, trig, pll, nco0, mixtail[2];
+    DevBuf<int8_t> carrier8;        // fast banks: the sign of the pilot band-pass output, one byte per IF sample
+    long cpitch = 0;
     int mix_cur = 0;
     // A stereo call walks the block in chunks on two internal streams: `wide` carries the front end, the band-pass pair and the
     // output stage of every chunk, `lanes` the PLL -- the PLL's few waves (one per 64 channels, a dependent chain each) leave
@@ -660,10 +706,10 @@ int launch_bpf(const StereoBank &b, long k_lo, long k_hi, hipStream_t s)
     const long wgs = (k_hi - k_lo + 64 * kR - 1) / (64 * kR);
     if (b.exact)
         hipLaunchKernelGGL((chs_bpf_kernel<T, true>), dim3(static_cast<unsigned>(wgs * b.n_channels)), dim3(64), 0, s, b.demod.p, b.dpitch,
-                           b.Hd, k_lo, k_hi, wgs, b.bpf_table.p, b.bpf.p, b.carrier.p, b.ypitch);
+                           b.Hd, k_lo, k_hi, wgs, b.bpf_table.p, b.bpf.p, b.carrier.p, b.ypitch, nullptr, 0L);
     else
         hipLaunchKernelGGL((chs_bpf_kernel<T, false>), dim3(static_cast<unsigned>(wgs * b.n_channels)), dim3(64), 0, s, b.demod.p, b.dpitch,
-                           b.Hd, k_lo, k_hi, wgs, b.bpf_table.p, b.bpf.p, b.carrier.p, b.ypitch);
+                           b.Hd, k_lo, k_hi, wgs, b.bpf_table.p, b.bpf.p, nullptr, b.ypitch, b.carrier8.p, b.cpitch);
     CHS_LAUNCH_CHECK("chs_bpf_kernel");
     return FMRX_OK;
 }
@@ -679,11 +725,11 @@ int launch_out(StereoBank &b, float *d_audio, int16_t *d_pcm, int wrap, long a_l
     if (b.exact)
         hipLaunchKernelGGL((chs_out_kernel<T, D, STEREO, true>), dim3(static_cast<unsigned>(wgs * b.n_channels)), dim3(64), 0, s, b.demod.p,
                            b.dpitch, b.Hd, b.bpf.p, b.trig.p, b.ypitch, b.nco0.p, b.mixtail[b.mix_cur].p, b.mixtail[b.mix_cur ^ 1].p, b.Hm,
-                           b.n_if, g_hi, b.delay, b.out_table.p, wgs, d_audio, d_pcm, wrap, a_lo, a_hi, b.n_audio);
+                           b.n_if, g_hi, b.delay, 2.0f, 0.0f, b.out_table.p, wgs, d_audio, d_pcm, wrap, a_lo, a_hi, b.n_audio);
     else if constexpr (STEREO)
         hipLaunchKernelGGL((chs_out_kernel<T, D, true, false>), dim3(static_cast<unsigned>(wgs * b.n_channels)), dim3(64), 0, s, b.demod.p,
                            b.dpitch, b.Hd, b.bpf.p, b.trig.p, b.ypitch, b.nco0.p, b.mixtail[b.mix_cur].p, b.mixtail[b.mix_cur ^ 1].p, b.Hm,
-                           b.n_if, g_hi, b.delay, b.out_table.p, wgs, d_audio, d_pcm, wrap, a_lo, a_hi, b.n_audio);
+                           b.n_if, g_hi, b.delay, 2.0f, 0.0f, b.out_table.p, wgs, d_audio, d_pcm, wrap, a_lo, a_hi, b.n_audio);
     CHS_LAUNCH_CHECK("chs_out_kernel");
     return FMRX_OK;
 }
@@ -795,10 +841,16 @@ int stereo_bank_create(StereoBank **out, const fmrx_params &p, int n_channels, i
 #define X(T_) if (p.stereo_taps == T_) FMRX_TRY(bpf_table_init<T_>(*b, hs.data(), hc.data()));
             CHS_BPF_CASES(X)
 #undef X
-            FMRX_TRY(b->carrier.alloc(b->ypitch * N + 64));
+            if (b->exact) {
+                FMRX_TRY(b->carrier.alloc(b->ypitch * N + 64));
+                FMRX_HIP(hipMemset(b->carrier.p, 0, b->carrier.bytes()));
+            } else {
+                b->cpitch = (b->n_if + 64 + 15) / 16 * 16;
+                FMRX_TRY(b->carrier8.alloc(b->cpitch * N + 64));
+                FMRX_HIP(hipMemset(b->carrier8.p, 0, b->carrier8.bytes()));
+            }
             FMRX_TRY(b->bpf.alloc(b->ypitch * N + 64));
             FMRX_TRY(b->trig.alloc(b->ypitch * N + 64));
-            FMRX_HIP(hipMemset(b->carrier.p, 0, b->carrier.bytes()));
             FMRX_TRY(b->pll.alloc(8 * N));
             FMRX_TRY(b->nco0.alloc(N));
             for (auto &m : b->mixtail) {
@@ -903,7 +955,12 @@ int stereo_bank_process_dev(StereoBank *b, float *d_audio, int16_t *d_pcm, int w
             FMRX_HIP(hipStreamWaitEvent(sl, b->ev_fork, 0));
             if (split) FMRX_HIP(hipStreamWaitEvent(sf, b->ev_fork, 0));
         }
-        for (int c = 0; c <= K; c++) {
+        // The output stage of chunk c follows the band-pass pair of chunk c + lag on the wide stream.  Exact banks: lag 1 (the PLL is
+        // the longest stage; nothing on the wide stream is waited for).  Fast banks: lag 2 -- the PLL of chunk c starts when its
+        // band-pass pair ends and takes longer than the next chunk's band-pass pair: with lag 1 the wide stream idled a third
+        // of the time waiting for it.
+        const int lag = (b->exact || K < 3) ? 1 : 2;
+        for (int c = 0; c < K + lag; c++) {
             if (c < K) {
                 const long a_lo = c * per, a_hi = a_lo + per < b->n_audio ? a_lo + per : b->n_audio;
                 const long k_lo = a_lo * p.audio_decim, k_hi = a_hi * p.audio_decim;
@@ -918,15 +975,21 @@ int stereo_bank_process_dev(StereoBank *b, float *d_audio, int16_t *d_pcm, int w
                     FMRX_HIP(hipStreamWaitEvent(sl, b->ev_bpf[c], 0));
                 }
                 // fmPLL(carrier_filt, 19 kHz, if_Fs, ncoScale 2, phaseAdjust 0, normBandwidth 0.01): src/project.cpp:237
-                FMRX_TRY(k_fm_pll_channels(b->carrier.p + k_lo, b->ypitch, static_cast<size_t>(k_hi - k_lo), b->n_channels, b->trig.p + k_lo,
-                                           b->ypitch, b->pll.p, c == 0 ? b->nco0.p : nullptr, 19e3f, static_cast<float>(p.if_Fs), 2.0f, 0.0f,
-                                           0.01f, sl, true, b->exact != 0));
+                if (b->exact)
+                    FMRX_TRY(k_fm_pll_channels(b->carrier.p + k_lo, b->ypitch, static_cast<size_t>(k_hi - k_lo), b->n_channels,
+                                               b->trig.p + k_lo, b->ypitch, b->pll.p, c == 0 ? b->nco0.p : nullptr, 19e3f,
+                                               static_cast<float>(p.if_Fs), 2.0f, 0.0f, 0.01f, sl, true, true));
+                else
+                    FMRX_TRY(k_fm_pll_channels(reinterpret_cast<const float *>(b->carrier8.p + k_lo), b->cpitch,
+                                               static_cast<size_t>(k_hi - k_lo), b->n_channels, b->trig.p + k_lo, b->ypitch, b->pll.p,
+                                               c == 0 ? b->nco0.p : nullptr, 19e3f, static_cast<float>(p.if_Fs), 2.0f, 0.0f, 0.01f, sl, true,
+                                               false, true));
                 if (K > 1) FMRX_HIP(hipEventRecord(b->ev_pll[c], sl));
             }
-            if (c > 0) {   // the output stage of the chunk before, behind this chunk's front end and band-pass pair on the wide stream
-                const long a_lo = (c - 1) * per, a_hi = a_lo + per < b->n_audio ? a_lo + per : b->n_audio;
-                if (K > 1) FMRX_HIP(hipStreamWaitEvent(sw, b->ev_pll[c - 1], 0));
-                FMRX_TRY(launch_nco(*b, a_lo * p.audio_decim, a_hi * p.audio_decim, sw));
+            if (c >= lag) {   // the output stage of an earlier chunk, behind this chunk's band-pass pair on the wide stream
+                const long a_lo = (c - lag) * per, a_hi = a_lo + per < b->n_audio ? a_lo + per : b->n_audio;
+                if (K > 1) FMRX_HIP(hipStreamWaitEvent(sw, b->ev_pll[c - lag], 0));
+                if (b->exact) FMRX_TRY(launch_nco(*b, a_lo * p.audio_decim, a_hi * p.audio_decim, sw));   // fast banks: inside the output stage
                 FMRX_TRY(out(a_lo, a_hi, a_hi * p.audio_decim, sw));
             }
         }
@@ -959,7 +1022,7 @@ int stereo_bank_read_tap(StereoBank *b, int channel, int which, float *out, size
     switch (which) {
     // the finish kernel has copied the row's tail into its front already; the block itself is intact
     case FMRX_TAP_DEMOD: src = b->demod.p + channel * b->dpitch + b->Hd; break;
-    case FMRX_TAP_CARRIER: if (b->audio_channels == 2) src = b->carrier.p + channel * b->ypitch; break;
+    case FMRX_TAP_CARRIER: if (b->audio_channels == 2 && b->exact) src = b->carrier.p + channel * b->ypitch; break;
     case FMRX_TAP_STEREO_BPF: if (b->audio_channels == 2) src = b->bpf.p + channel * b->ypitch; break;
     case FMRX_TAP_PLL: if (b->audio_channels == 2) { src = b->trig.p + channel * b->ypitch; cnt = n_if + 1; } break;
     default: break;
@@ -970,6 +1033,8 @@ int stereo_bank_read_tap(StereoBank *b, int channel, int which, float *out, size
     if (which == FMRX_TAP_PLL) {
         FMRX_HIP(hipMemcpy(out, b->nco0.p + channel, sizeof(float), hipMemcpyDeviceToHost));
         FMRX_HIP(hipMemcpy(out + 1, src, n_if * sizeof(float), hipMemcpyDeviceToHost));
+        if (!b->exact)   // the fast bank keeps the raw trigArg of every step (the cosine is taken inside the output stage)
+            for (size_t k = 1; k <= n_if; k++) out[k] = std::cos(out[k] * 2.0f + 0.0f);
         return FMRX_OK;
     }
     FMRX_HIP(hipMemcpy(out, src, cnt * sizeof(float), hipMemcpyDeviceToHost));

@@ -285,7 +285,8 @@ size_t pll_parallel_lti_floats(size_t n);
 int k_fm_pll_channels(const float *d_in, long pitch_in, size_t n, int n_ch, float *d_trig, long pitch_trig, float *d_state,
                       float *d_nco0, float freq, float Fs, float ncoScale, float phaseAdjust, float normBandwidth, hipStream_t s,
                       bool flat = true,    // flat: the branch-free forms of glibc's functions (same values; false = A/B)
-                      bool exact = true);  // false: the fast recurrence (closed-form phase detector, hardware sine / cosine) of the specialised path
+                      bool exact = true,   // false: the fast recurrence (closed-form phase detector, hardware sine / cosine) of the specialised path
+                      bool in8 = false);   // fast only: d_in holds signed bytes (the input's sign; pitch_in in bytes)
 int k_mix(const float *d_bpf, const float *d_pll, size_t n, float *d_mix, hipStream_t s);
 int k_combine(const float *d_st, const float *d_mono, size_t n, float *d_l, float *d_r, hipStream_t s);
 int k_upsample(const float *d_x, size_t n, float *d_xu, int up, hipStream_t s);

@@ -695,7 +695,10 @@ __global__ __launch_bounds__(kRepairThreads) void pll_repair_kernel(
 // channel, the reference's six first; nco0[channel] = PLL[0] of this call = the incoming state's lastOut.
 // Rows are 16-byte aligned with >= 16 readable floats behind their n samples (host contract): the input is fetched as
 // 16-byte groups three groups ahead of the chain.
-template <int MATH, bool FLAT>
+// IN8 (fast bank): the input is the SIGN of the pilot band-pass output, one signed byte per sample (+1 / -1; 0 = a sample that
+// is zero, denormal-small or not finite) -- all the fast recurrence reads of an ordinary sample is its sign (pll_step_clean), and a
+// byte instead of a float per IF sample is 0.6 of the bank's 6 bytes of HBM traffic per input sample.
+template <int MATH, bool FLAT, bool IN8 = false>
 __global__ __launch_bounds__(64, 1) void pll_channels_kernel(const float *__restrict__ in, long pitch_in, long n, long n_ch,
                                                            float *__restrict__ trig, long pitch_trig, float *__restrict__ state,
                                                            float *__restrict__ nco0, PllCoef c)
@@ -717,7 +720,9 @@ __global__ __launch_bounds__(64, 1) void pll_channels_kernel(const float *__rest
     if (MATH == kFast) s.fr = atan2f(st[3], st[2]) * 0.15915494309189533577f;
     if (nco0) nco0[ch] = s.last;
     const f4 *in4 = reinterpret_cast<const f4 *>(in + ch * pitch_in);
+    const int8_t *in8 = reinterpret_cast<const int8_t *>(in) + ch * pitch_in;    // IN8: pitch in bytes
     f4 *out4 = reinterpret_cast<f4 *>(trig + ch * pitch_trig);
+    typedef int i4v __attribute__((ext_vector_type(4)));
     // four steps of the recurrence: the samples in, the raw trigArg of each step out
     auto four = [&](const f4 cur) __attribute__((always_inline)) -> f4 {   // (called twice: outlined, the state would live in scratch)
         f4 r;
@@ -753,20 +758,36 @@ __global__ __launch_bounds__(64, 1) void pll_channels_kernel(const float *__rest
     // from LDS behind the next requests.  (The compiler waits for ALL outstanding global accesses where it needs one of them:
     // with loads and stores inside the loop of steps every group of four steps paid a memory round trip.)
     const long nb = n / kBatch;
-    f4 pre[kBatch / 4];
+    f4 pre[IN8 ? 1 : kBatch / 4];
+    i4v pre8[2];                                               // IN8: 32 signed bytes
     if (nb > 0) {
+        if (IN8) {
+            pre8[0] = reinterpret_cast<const i4v *>(in8)[0];
+            pre8[1] = reinterpret_cast<const i4v *>(in8)[1];
+        } else {
 #pragma unroll
-        for (int g = 0; g < kBatch / 4; g++) pre[g] = in4[g];
+            for (int g = 0; g < kBatch / 4; g++) pre[g] = in4[g];
+        }
     }
     for (long b = 0; b < nb; b++) {
         // (1) this batch's input -> LDS (requested a batch ago); (2) request the next batch
+        if (IN8) {
 #pragma unroll
-        for (int g = 0; g < kBatch / 4; g++)
+            for (int j = 0; j < kBatch; j++)
+                lin[j * 64 + lane] = static_cast<float>(static_cast<int8_t>((pre8[j / 16][(j / 4) % 4] >> (8 * (j % 4))) & 0xff));
+            if (b + 1 < nb) {
+                pre8[0] = reinterpret_cast<const i4v *>(in8 + (b + 1) * kBatch)[0];
+                pre8[1] = reinterpret_cast<const i4v *>(in8 + (b + 1) * kBatch)[1];
+            }
+        } else {
 #pragma unroll
-            for (int e = 0; e < 4; e++) lin[(4 * g + e) * 64 + lane] = pre[g][e];
-        if (b + 1 < nb) {
+            for (int g = 0; g < kBatch / 4; g++)
 #pragma unroll
-            for (int g = 0; g < kBatch / 4; g++) pre[g] = in4[(b + 1) * (kBatch / 4) + g];
+                for (int e = 0; e < 4; e++) lin[(4 * g + e) * 64 + lane] = pre[g][e];
+            if (b + 1 < nb) {
+#pragma unroll
+                for (int g = 0; g < kBatch / 4; g++) pre[g] = in4[(b + 1) * (kBatch / 4) + g];
+            }
         }
         // (3) the previous batch's output -> memory (its stores have this whole batch to complete)
         if (b > 0) {
@@ -798,9 +819,12 @@ __global__ __launch_bounds__(64, 1) void pll_channels_kernel(const float *__rest
     }
     // what is left of a block that is not a multiple of the batch: groups of four, then single samples
     long k = nb * kBatch;
-    for (; k + 4 <= n; k += 4) out4[k / 4] = four(in4[k / 4]);
+    for (; k + 4 <= n; k += 4)
+        out4[k / 4] = four(IN8 ? (f4){static_cast<float>(in8[k]), static_cast<float>(in8[k + 1]), static_cast<float>(in8[k + 2]),
+                                      static_cast<float>(in8[k + 3])}
+                               : in4[k / 4]);
     for (; k < n; k++) {
-        pll_step<MATH>(s, in[ch * pitch_in + k], c);
+        pll_step<MATH>(s, IN8 ? static_cast<float>(in8[k]) : in[ch * pitch_in + k], c);
         trig[ch * pitch_trig + k] = s.last;
     }
     finish_state<MATH>(s, c);
@@ -878,14 +902,17 @@ int k_fm_pll(const float *d_in, size_t n, float *d_out, float *d_state, float fr
 
 int k_fm_pll_channels(const float *d_in, long pitch_in, size_t n, int n_ch, float *d_trig, long pitch_trig, float *d_state,
                       float *d_nco0, float freq, float Fs, float ncoScale, float phaseAdjust, float normBandwidth, hipStream_t s, bool flat,
-                      bool exact)
+                      bool exact, bool in8)
 {
     if (n == 0 || n_ch <= 0) return FMRX_OK;
-    if (reinterpret_cast<uintptr_t>(d_in) % 16 || reinterpret_cast<uintptr_t>(d_trig) % 16 || pitch_in % 4 || pitch_trig % 4 ||
-        pitch_in < static_cast<long>(n) + 16)
-        return fail(FMRX_EINVAL, "fm_pll_channels: rows must be 16-byte aligned with 16 readable floats behind their samples");
+    if (reinterpret_cast<uintptr_t>(d_in) % 16 || reinterpret_cast<uintptr_t>(d_trig) % 16 || pitch_in % (in8 ? 16 : 4) || pitch_trig % 4 ||
+        pitch_in < static_cast<long>(n) + 16 || (in8 && exact))
+        return fail(FMRX_EINVAL, "fm_pll_channels: rows must be 16-byte aligned with 16 readable samples behind their own");
     const PllCoef c = make_coef(freq, Fs, ncoScale, phaseAdjust, normBandwidth);
-    if (!exact)
+    if (in8)
+        hipLaunchKernelGGL((pll_channels_kernel<kFast, false, true>), dim3(static_cast<unsigned>((n_ch + 63) / 64)), dim3(64), 0, s, d_in,
+                           pitch_in, static_cast<long>(n), static_cast<long>(n_ch), d_trig, pitch_trig, d_state, d_nco0, c);
+    else if (!exact)
         hipLaunchKernelGGL((pll_channels_kernel<kFast, false>), dim3(static_cast<unsigned>((n_ch + 63) / 64)), dim3(64), 0, s, d_in, pitch_in,
                            static_cast<long>(n), static_cast<long>(n_ch), d_trig, pitch_trig, d_state, d_nco0, c);
     else if (flat)

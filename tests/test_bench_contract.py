@@ -58,6 +58,7 @@ def test_bench_json_contract(fmrx):
     assert out["legs"]["mode0_stereo_exact"]["tolerance"].startswith("bit-exact")
     bank = out["legs"]["stereo_channels_exact"]
     assert bank["tolerance"].startswith("bit-exact") and bank["value"] > 1e4 and bank["channels"] >= 256
+    assert out["legs"]["stereo_channels"]["value"] > bank["value"] and "ulp(trigArg" in out["legs"]["stereo_channels"]["tolerance"]
     # the CPU figure beside every mode's leg
     for k in ("mode1_mono", "mode2_mono", "mode3_mono", "mode0_stereo"):
         assert c["legs"][k]["value"] > 0.5 and c["legs"][k]["cores"] == 1
