@@ -279,6 +279,7 @@ def leg(name, what, n_samples, ms, bytes_per_sample, extra=None):
 def side_legs(torch, fmrx, synth, args, pl, step, d_iq, n_bytes, stream) -> dict:
     """N=1 only, after the timed region: the other configurations and kernels of the path, each with its
     algorithmic bytes per sample, device time per step and fraction of the HBM peak."""
+    import numpy as np
     legs = {}
     n_samples = n_bytes // 2
     k = max(10, min(args.steps, 30))
@@ -453,6 +454,41 @@ def side_legs(torch, fmrx, synth, args, pl, step, d_iq, n_bytes, stream) -> dict
     ms = event_ms(torch, lambda: q.process_dev(d_iq.data_ptr(), 102400, None, d_pcm.data_ptr(), wrap=True, stream=stream), 200, warm=20)
     legs["small_block"]["fused_kernel_us_per_block"] = round(ms * 1e3, 2)
     q.close()
+    # (5a) PCIe-inclusive figures (never `value`): host buffers through fmrx_pipeline_submit / _wait (two blocks in flight, page-locked
+    #      memory), 1,024,000-sample blocks; and the drop-in CLI, stdin -> stdout, from and to /dev/shm
+    try:   # a process of its own (started, not exec'ed): this one has created dozens of streams by now, and HIP deals streams
+           # round-robin onto a few hardware queues -- the probe's two streams must not share one
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pcie_probe.py"), "--json"], capture_output=True, text=True, timeout=300)
+        pj = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        two, one = pj["1024000_samples_two_in_flight"], pj["1024000_samples_synchronous"]
+        legs["host_buffers"] = {
+            "what": "mode 0 mono, 1,024,000-sample blocks from page-locked HOST memory, s16 back to host: fmrx_pipeline_submit / _wait "
+                    "(two blocks in flight: a block's H2D under its neighbour's kernels and D2H); PCIe-inclusive, wall clock, own process "
+                    "(tools/pcie_probe.py)",
+            "ms_per_block": two["ms_per_block"], "value": two["MS_per_s"], "unit": "MS/s", "h2d_GBs": two["h2d_GBs"],
+            "synchronous_process_ms_per_block": one["ms_per_block"], "synchronous_h2d_GBs": one["h2d_GBs"],
+            "bare_pinned_h2d_2MB_GBs": pj.get("bare_pinned_h2d_2048000_bytes_GBs"), "larger_blocks": {k: v for k, v in pj.items() if k.startswith(("4096000", "16384000"))}}
+    except Exception as e:
+        legs["host_buffers"] = {"error": str(e)}
+    try:
+        cli = os.path.join(ROOT, "software-defined-radio_amd", "lib", "fmrx_project")
+        path = "/dev/shm/fmrx_bench_iq.raw"
+        nbytes = 0
+        with open(path, "wb") as f:
+            blk = d_iq[:2 * BLOCK_SAMPLES * 4].cpu().numpy().tobytes()
+            for _ in range(64):
+                f.write(blk); nbytes += len(blk)
+        t0 = time.perf_counter()
+        r = subprocess.run(f"{cli} 0 1 --blocks-per-call 20 < {path} > /dev/shm/fmrx_bench_pcm.raw", shell=True, capture_output=True)
+        dt = time.perf_counter() - t0
+        out_bytes = os.path.getsize("/dev/shm/fmrx_bench_pcm.raw")
+        legs["cli_stdin_stdout"] = {
+            "what": "the drop-in CLI: fmrx_project 0 1 --blocks-per-call 20 < /dev/shm/iq.raw > /dev/shm/pcm.raw (process start, device "
+                    "initialisation and pipe I/O included), mode 0 mono", "input_bytes": nbytes, "output_bytes": out_bytes, "seconds": round(dt, 3),
+            "value": round(nbytes / 2 / dt / 1e6, 1), "unit": "MS/s", "rc": r.returncode}
+        os.remove(path); os.remove("/dev/shm/fmrx_bench_pcm.raw")
+    except Exception as e:
+        legs["cli_stdin_stdout"] = {"error": str(e)}
     # (5b) the same regime done properly: the current reference-size block of N live channels in ONE launch
     #      (fmrx_channels_*; every channel's state is its last bytes, csrc/channels.hip)
     nch = 4096

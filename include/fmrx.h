@@ -238,6 +238,14 @@ FMRX_API size_t fmrx_pipeline_n_audio(const fmrx_pipeline *pl, size_t n_bytes);
  * n_if*upsamp % decim == 0) and n_bytes/2 >= rf_taps-1. */
 FMRX_API int fmrx_pipeline_process(fmrx_pipeline *pl, const uint8_t *iq, size_t n_bytes, float *audio_f32,
                                    int16_t *pcm16, int pcm_policy);
+/* The same call in two halves, for block-streaming callers that want the PCIe copies of one block under the kernels of its
+ * neighbours: submit enqueues one block (copy in, kernels, copy out) and returns; wait blocks until the OLDEST submitted block's
+ * outputs are complete in the host buffers passed to its submit.  At most two blocks are in flight (a third submit waits
+ * for the oldest first).  Buffers must stay valid until their block has been waited for; page-locked buffers (fmrx_host_alloc)
+ * make the copies truly asynchronous.  fmrx_pipeline_process = submit + wait.  Results are identical to the synchronous calls'. */
+FMRX_API int fmrx_pipeline_submit(fmrx_pipeline *pl, const uint8_t *iq, size_t n_bytes, float *audio_f32, int16_t *pcm16,
+                                  int pcm_policy);
+FMRX_API int fmrx_pipeline_wait(fmrx_pipeline *pl);
 /* Same, device-resident: d_iq is DEVICE memory (16-byte aligned), outputs are
  * DEVICE memory or NULL; asynchronous on `stream` (a hipStream_t).  This is
  * the entry point the throughput figures are measured on.  (With option

@@ -105,6 +105,8 @@ _sig("fmrx_pipeline_n_if", [_vp, _sz], _sz)
 _sig("fmrx_pipeline_n_audio", [_vp, _sz], _sz)
 _sig("fmrx_pipeline_process", [_vp, _u8p, _sz, _vp, _vp, _int])
 _sig("fmrx_pipeline_process_dev", [_vp, _vp, _sz, _vp, _vp, _int, _vp])
+_sig("fmrx_pipeline_submit", [_vp, _vp, _sz, _vp, _vp, _int])
+_sig("fmrx_pipeline_wait", [_vp])
 _sig("fmrx_pipeline_read_tap", [_vp, _int, _vp, C.POINTER(_sz)])
 _sig("fmrx_pipeline_state_size", [_vp], _sz)
 _sig("fmrx_pipeline_get_state", [_vp, _f32p, _sz])
@@ -196,6 +198,25 @@ def get_option(name: str) -> int:
 def diagStreamRead(d_ptr, n_bytes, method=0, stream=None) -> None:
     """One pure streaming read of a device buffer (fmrx_diag_stream_read_dev), async on `stream`."""
     _check(lib.fmrx_diag_stream_read_dev(d_ptr, n_bytes, method, stream))
+
+
+def hostAlloc(nbytes: int, dtype=np.uint8) -> np.ndarray:
+    """A page-locked host buffer (fmrx_host_alloc) as a numpy array of `dtype`; free it with hostFree(arr)."""
+    p = _vp()
+    _check(lib.fmrx_host_alloc(C.byref(p), int(nbytes)))
+    buf = (C.c_uint8 * int(nbytes)).from_address(p.value)
+    arr = np.frombuffer(buf, dtype=dtype)
+    arr.flags.writeable = True
+    _PINNED[arr.ctypes.data] = (p.value, buf)
+    return arr
+
+
+def hostFree(arr: np.ndarray) -> None:
+    p, _ = _PINNED.pop(arr.ctypes.data)
+    _check(lib.fmrx_host_free(p))
+
+
+_PINNED: dict = {}
 
 
 def deviceLibm(fn: str, a, b=None, flat=False) -> np.ndarray:
@@ -447,6 +468,14 @@ class Pipeline:
         else:
             out["audio_l"], out["audio_r"] = f[:na], f[na:]
         return out
+
+    def submit(self, iq_ptr, n_bytes, audio_ptr=None, pcm_ptr=None, wrap=True):
+        """fmrx_pipeline_submit on raw HOST addresses (e.g. page-locked buffers from hostAlloc): enqueue and return."""
+        _check(lib.fmrx_pipeline_submit(self._h, iq_ptr, n_bytes, audio_ptr, pcm_ptr, PCM_WRAP if wrap else PCM_SATURATE))
+
+    def wait(self):
+        """fmrx_pipeline_wait: the oldest submitted block's outputs are complete."""
+        _check(lib.fmrx_pipeline_wait(self._h))
 
     def process_dev(self, d_iq_ptr, n_bytes, d_audio_ptr=None, d_pcm_ptr=None, wrap=True, stream=None):
         """Device-resident block: raw device addresses (e.g. torch.Tensor.data_ptr()); async on `stream`."""

@@ -163,18 +163,40 @@ int main(int argc, char *argv[])
     });
 
     const size_t n_out = fmrx_pipeline_n_audio(pl, block_bytes) * channels;
-    int16_t *pcm = nullptr;
-    {
+    int16_t *pcm[2] = {nullptr, nullptr};
+    for (auto &q : pcm) {
         void *ptr = nullptr;
         if (fmrx_host_alloc(&ptr, n_out * sizeof(int16_t)) != FMRX_OK) {
             std::fprintf(stderr, "fmrx: %s\n", fmrx_last_error());
             return 2;
         }
-        pcm = static_cast<int16_t *>(ptr);
+        q = static_cast<int16_t *>(ptr);
     }
+    // Two blocks in flight (fmrx_pipeline_submit / _wait): block i+1's copy to the device and its kernels run while block i's
+    // PCM is copied back and written to stdout.  Output order = input order.
     size_t blocks = 0;
     int rc = 0;
-    for (;;) {
+    struct InFlight { int idx; size_t bytes; bool valid; } fl[2] = {{0, 0, false}, {0, 0, false}};
+    auto retire = [&](int slot) {   // the block submitted into `slot`: wait, write its PCM, give its input buffer back
+        if (!fl[slot].valid) return;
+        fl[slot].valid = false;
+        const size_t n_pcm = fmrx_pipeline_n_audio(pl, fl[slot].bytes) * channels;
+        if (fmrx_pipeline_wait(pl) != FMRX_OK) {
+            std::fprintf(stderr, "fmrx: %s\n", fmrx_last_error());
+            rc = 3;
+        } else if (std::fwrite(pcm[slot], sizeof(int16_t), n_pcm, stdout) != n_pcm) {
+            std::fprintf(stderr, "fmrx: short write on stdout\n");
+            rc = 4;
+        }
+        {
+            std::lock_guard<std::mutex> lk(bq.m);
+            bq.free_.push(fl[slot].idx);
+            bq.cv.notify_all();
+        }
+        if (!rc) blocks += fl[slot].bytes / static_cast<size_t>(p.block_bytes);
+    };
+    int slot = 0;                                           // the slot the next submission uses; it alternates
+    for (;; slot ^= 1) {
         int idx;
         size_t bytes;
         {
@@ -185,23 +207,19 @@ int main(int argc, char *argv[])
             bytes = bq.full.front().second;
             bq.full.pop();
         }
-        const size_t n_pcm = fmrx_pipeline_n_audio(pl, bytes) * channels;
-        if (fmrx_pipeline_process(pl, pool[idx], bytes, nullptr, pcm,
-                                  saturate ? FMRX_PCM_SATURATE : FMRX_PCM_WRAP) != FMRX_OK) {
+        retire(slot);                                       // the block that used this slot two submissions ago
+        if (rc) break;
+        if (fmrx_pipeline_submit(pl, pool[idx], bytes, nullptr, pcm[slot], saturate ? FMRX_PCM_SATURATE : FMRX_PCM_WRAP) != FMRX_OK) {
             std::fprintf(stderr, "fmrx: %s\n", fmrx_last_error());
             rc = 3;
-        } else if (std::fwrite(pcm, sizeof(int16_t), n_pcm, stdout) != n_pcm) {
-            std::fprintf(stderr, "fmrx: short write on stdout\n");
-            rc = 4;
+            break;
         }
-        {
-            std::lock_guard<std::mutex> lk(bq.m);
-            bq.free_.push(idx);
-            bq.cv.notify_all();
-        }
-        if (rc) break;
-        blocks += bytes / static_cast<size_t>(p.block_bytes);
+        fl[slot] = {idx, bytes, true};
     }
+    // drain in submission order (fmrx_pipeline_wait retires the oldest block first): `slot` is the one that would be
+    // reused next, i.e. it holds the older of the two
+    if (!rc) retire(slot);
+    if (!rc) retire(slot ^ 1);
     if (rc != 0) {  // retire the producer
         std::lock_guard<std::mutex> lk(bq.m);
         bq.done = true;
@@ -212,7 +230,7 @@ int main(int argc, char *argv[])
     std::fprintf(stderr, "End of input stream reached after %zu reference-size blocks\n", blocks);
     fmrx_pipeline_destroy(pl);
     for (auto *b : pool) fmrx_host_free(b);
-    fmrx_host_free(pcm);
+    for (auto *q : pcm) fmrx_host_free(q);
     if (rc) return rc;
     return compat_exit ? 1 : 0;
 }

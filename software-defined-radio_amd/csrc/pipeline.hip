@@ -83,6 +83,17 @@ struct fmrx_pipeline {
     int mix_cur = 0;
     DevBuf<float> out_f32;
     DevBuf<int16_t> out_pcm;
+    // asynchronous host-buffer calls (fmrx_pipeline_submit / _wait): two slots, each with its own stream and device staging
+    // buffers (slot 0 = `stream`, `in`, `out_f32`, `out_pcm` above): block i+1's copy to the device runs under block i's kernels
+    // and block i-1's copy back.  Only the kernels of consecutive blocks are ordered (they carry the state): ev_kern.
+    hipStream_t stream2 = nullptr;
+    DevBuf<uint8_t> in2;
+    DevBuf<float> out_f32_2;
+    DevBuf<int16_t> out_pcm_2;
+    hipEvent_t ev_kern[2] = {}, ev_done[2] = {};
+    bool slot_busy[2] = {false, false};
+    int next_slot = 0, oldest_slot = 0, last_kern_slot = -1;
+    bool async_ready = false;
 
     size_t last_n_if = 0, last_n_audio = 0;
     const float *last_mono = nullptr;   // where the last block's mono audio was written
@@ -140,6 +151,9 @@ int audio_stage(fmrx_pipeline *pl, const float *d_x, size_t n_in, int delay, flo
 
 int reset_state(fmrx_pipeline *pl)
 {
+    pl->slot_busy[0] = pl->slot_busy[1] = false;   // the device-wide wait below retires whatever was submitted
+    pl->next_slot = pl->oldest_slot = 0;
+    pl->last_kern_slot = -1;
     // process_dev runs on the caller's stream: whatever is still in flight there must not see the
     // state change under it (reset is rare; a device-wide wait is the simple, safe order)
     FMRX_HIP(hipDeviceSynchronize());
@@ -294,6 +308,14 @@ int fmrx_pipeline_destroy(fmrx_pipeline *pl)
     for (auto &q : pl->ev)
         for (auto &e : q)
             if (e) (void)hipEventDestroy(e);
+    if (pl->stream2) {
+        (void)hipStreamSynchronize(pl->stream2);
+        (void)hipStreamDestroy(pl->stream2);
+    }
+    for (auto &e : pl->ev_kern)
+        if (e) (void)hipEventDestroy(e);
+    for (auto &e : pl->ev_done)
+        if (e) (void)hipEventDestroy(e);
     for (auto &st : pl->ov_stream)
         if (st) {
             (void)hipStreamSynchronize(st);
@@ -654,25 +676,73 @@ int fmrx_pipeline_process_dev(fmrx_pipeline *pl, const uint8_t *d_iq, size_t n_b
     return FMRX_OK;
 }
 
+static int async_setup(fmrx_pipeline *pl)
+{
+    if (pl->async_ready) return FMRX_OK;
+    const size_t n_au = n_audio_of(pl, pl->max_bytes) + 1;
+    FMRX_TRY(pl->in2.ensure(pl->in.n));
+    FMRX_TRY(pl->out_f32_2.ensure(2 * n_au));
+    FMRX_TRY(pl->out_pcm_2.ensure(2 * n_au));
+    if (!pl->stream2) FMRX_HIP(hipStreamCreateWithFlags(&pl->stream2, hipStreamNonBlocking));
+    for (auto &e : pl->ev_kern)
+        if (!e) FMRX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &e : pl->ev_done)
+        if (!e) FMRX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    pl->async_ready = true;
+    return FMRX_OK;
+}
+
+int fmrx_pipeline_wait(fmrx_pipeline *pl)
+{
+    if (!pl) return fail(FMRX_EINVAL, "wait: null handle");
+    const int slot = pl->oldest_slot;
+    if (!pl->slot_busy[slot]) return FMRX_OK;
+    FMRX_HIP(hipSetDevice(pl->device));
+    FMRX_HIP(hipEventSynchronize(pl->ev_done[slot]));
+    pl->slot_busy[slot] = false;
+    pl->oldest_slot = slot ^ 1;
+    return FMRX_OK;
+}
+
+int fmrx_pipeline_submit(fmrx_pipeline *pl, const uint8_t *iq, size_t n_bytes, float *audio_f32, int16_t *pcm16, int pcm_policy)
+{
+    if (!pl || !iq) return fail(FMRX_EINVAL, "submit: null argument");
+    FMRX_TRY(check_block(pl, n_bytes));
+    FMRX_HIP(hipSetDevice(pl->device));
+    FMRX_TRY(async_setup(pl));
+    const int slot = pl->next_slot;
+    if (pl->slot_busy[slot]) FMRX_TRY(fmrx_pipeline_wait(pl));   // two blocks in flight: the older one first
+    hipStream_t s = slot ? pl->stream2 : pl->stream;
+    uint8_t *d_in = slot ? pl->in2.p : pl->in.p;
+    float *d_f32 = slot ? pl->out_f32_2.p : pl->out_f32.p;
+    int16_t *d_pcm = slot ? pl->out_pcm_2.p : pl->out_pcm.p;
+    const size_t n_au = n_audio_of(pl, n_bytes);
+    const size_t nch = pl->channels;
+    FMRX_HIP(hipMemcpyAsync(d_in, iq, n_bytes, hipMemcpyHostToDevice, s));
+    // option overlap_calls vouches for inputs that are complete at the call; this one is still on its way: wait for it
+    if (pl->opt.overlap_calls != 0) FMRX_HIP(hipStreamSynchronize(s));
+    // the kernels of consecutive blocks carry the receiver's state: this block's follow the previous block's (the copies do not)
+    if (pl->last_kern_slot >= 0 && pl->last_kern_slot != slot) FMRX_HIP(hipStreamWaitEvent(s, pl->ev_kern[pl->last_kern_slot], 0));
+    FMRX_TRY(fmrx_pipeline_process_dev(pl, d_in, n_bytes, audio_f32 ? d_f32 : nullptr, pcm16 ? d_pcm : nullptr, pcm_policy, s));
+    FMRX_HIP(hipEventRecord(pl->ev_kern[slot], s));
+    pl->last_kern_slot = slot;
+    if (audio_f32) FMRX_HIP(hipMemcpyAsync(audio_f32, d_f32, nch * n_au * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (pcm16) FMRX_HIP(hipMemcpyAsync(pcm16, d_pcm, nch * n_au * sizeof(int16_t), hipMemcpyDeviceToHost, s));
+    FMRX_HIP(hipEventRecord(pl->ev_done[slot], s));
+    pl->slot_busy[slot] = true;
+    pl->next_slot = slot ^ 1;
+    if (!pl->slot_busy[slot ^ 1]) pl->oldest_slot = slot;
+    return FMRX_OK;
+}
+
 int fmrx_pipeline_process(fmrx_pipeline *pl, const uint8_t *iq, size_t n_bytes, float *audio_f32, int16_t *pcm16,
                           int pcm_policy)
 {
     if (!pl || !iq) return fail(FMRX_EINVAL, "process: null argument");
-    FMRX_TRY(check_block(pl, n_bytes));
-    FMRX_HIP(hipSetDevice(pl->device));
-    hipStream_t s = pl->stream;
-    const size_t n_au = n_audio_of(pl, n_bytes);
-    const size_t nch = pl->channels;
-    FMRX_HIP(hipMemcpyAsync(pl->in.p, iq, n_bytes, hipMemcpyHostToDevice, s));
-    // option overlap_calls vouches for inputs that are complete at the call; this one is still on its way: wait for it (the
-    // call ends with a wait anyway, so nothing of the option's gain exists here to lose)
-    if (pl->opt.overlap_calls != 0) FMRX_HIP(hipStreamSynchronize(s));
-    FMRX_TRY(fmrx_pipeline_process_dev(pl, pl->in.p, n_bytes, audio_f32 ? pl->out_f32.p : nullptr,
-                                       pcm16 ? pl->out_pcm.p : nullptr, pcm_policy, s));
-    if (audio_f32) FMRX_HIP(hipMemcpyAsync(audio_f32, pl->out_f32.p, nch * n_au * sizeof(float), hipMemcpyDeviceToHost, s));
-    if (pcm16) FMRX_HIP(hipMemcpyAsync(pcm16, pl->out_pcm.p, nch * n_au * sizeof(int16_t), hipMemcpyDeviceToHost, s));
-    FMRX_HIP(hipStreamSynchronize(s));
-    return FMRX_OK;
+    // the synchronous form = submit + wait for everything in flight (so mixing the two forms keeps the stream's order)
+    FMRX_TRY(fmrx_pipeline_submit(pl, iq, n_bytes, audio_f32, pcm16, pcm_policy));
+    FMRX_TRY(fmrx_pipeline_wait(pl));
+    return fmrx_pipeline_wait(pl);
 }
 
 int fmrx_pipeline_read_tap(fmrx_pipeline *pl, int which, float *out, size_t *n)

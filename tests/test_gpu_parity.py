@@ -1286,3 +1286,35 @@ def test_arctan_demodulator(fmrx, oracle):
             assert_audio_close(out["audio"], y, f"{fe} block {b}")
     with pytest.raises(fmrx.FmrxError):
         pl.set_option("demod", 2)
+
+
+@pytest.mark.parametrize("channels", [1, 2])
+def test_submit_wait_is_process(fmrx, oracle, channels):
+    """fmrx_pipeline_submit / _wait (two host blocks in flight: a block's PCIe copies under its neighbours' kernels) produce what
+    the synchronous fmrx_pipeline_process produces, bit for bit, block after block -- page-locked buffers, reference-size
+    blocks and 1,024,000-sample blocks, mono and stereo."""
+    for bb, nblk in ((102400, 7), (2 * 1024000, 4)):
+        iq = oracle.synth_fm_u8(bb // 2 * nblk, seed=77)
+        a, b = fmrx.Pipeline(0, channels, max_block_bytes=bb), fmrx.Pipeline(0, channels, max_block_bytes=bb)
+        na = a.n_audio(bb) * channels
+        h_in = fmrx.hostAlloc(len(iq))
+        h_in[:] = iq
+        h_f32 = fmrx.hostAlloc(4 * na * nblk, np.float32)
+        h_pcm = fmrx.hostAlloc(2 * na * nblk, np.int16)
+        for k in range(nblk):
+            a.submit(h_in.ctypes.data + k * bb, bb, h_f32.ctypes.data + 4 * na * k, h_pcm.ctypes.data + 2 * na * k)
+            if k >= 1:
+                a.wait()                                   # block k-1 is complete; block k is in flight
+                want = b.process(iq[(k - 1) * bb:k * bb])
+                f = h_f32[(k - 1) * na:k * na]
+                bits_equal(f, np.concatenate([want["audio_l"], want["audio_r"]]) if channels == 2 else want["audio"], f"block {k - 1}")
+                bits_equal(h_pcm[(k - 1) * na:k * na], want["pcm16"])
+        a.wait()
+        want = b.process(iq[(nblk - 1) * bb:])
+        bits_equal(h_pcm[(nblk - 1) * na:], want["pcm16"])
+        a.wait()                                           # nothing in flight: returns at once
+        # the synchronous call after asynchronous ones continues the same stream
+        more = oracle.synth_fm_u8(bb // 2, seed=78)
+        bits_equal(a.process(more)["pcm16"], b.process(more)["pcm16"])
+        for h in (h_in, h_f32, h_pcm):
+            fmrx.hostFree(h)
