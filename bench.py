@@ -283,6 +283,23 @@ def side_legs(torch, fmrx, synth, args, pl, step, d_iq, n_bytes, stream) -> dict
     legs = {}
     n_samples = n_bytes // 2
     k = max(10, min(args.steps, 30))
+    # (0) the headline step at 8x the Infinity Cache: 1024 blocks = 2.1 GB of input resident per step (the default 524 MB is only 2x the
+    #     256 MiB last-level cache; a cyclic sweep should not profit from it, and this leg shows whether it does).  Measured first,
+    #     in the thermal state of the headline (the vector-ALU legs below pull the clocks down for a while)
+    try:
+        big = d_iq.repeat(1024 * BLOCK_SAMPLES * 2 // n_bytes) if (1024 * BLOCK_SAMPLES * 2) % n_bytes == 0 else None
+        if big is not None:
+            q = fmrx.Pipeline(0, 1, rf_taps=101, base_audio_taps=101, max_block_bytes=big.numel(), device=torch.cuda.current_device())
+            d_pcm_big = torch.empty(q.n_audio(big.numel()), dtype=torch.int16, device="cuda")
+            ms = event_ms(torch, lambda: q.process_dev(big.data_ptr(), big.numel(), None, d_pcm_big.data_ptr(), wrap=True, stream=stream), 10, warm=5)
+            name, d = leg("mono_1024_blocks", "the headline step with 1024 x 1,024,000-sample blocks (2.1 GB of u8 I/Q, 8 x the 256 MiB Infinity Cache) "
+                          "resident per step: mono_fused_kernel<101,10,101,5>, s16 out", big.numel() // 2, ms, S3_BYTES)
+            legs[name] = d
+            q.close()
+            del q, big, d_pcm_big
+            torch.cuda.empty_cache()
+    except Exception as e:
+        legs["mono_1024_blocks"] = {"error": str(e)}
     # (1) the same workload through the vector-ALU kernels: the north star's "no MFMA" form (S2 + audio kernel)
     pl.set_option("fe_variant", "valu")
     ms = event_ms(torch, step, k, warm=100)
@@ -300,22 +317,6 @@ def side_legs(torch, fmrx, synth, args, pl, step, d_iq, n_bytes, stream) -> dict
         "frac": round(S2_BYTES * n_samples / (fe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "steps": k,
         "note": "avg_launch_ms = step time minus the audio kernel's event-bracketed time"}
     pl.set_option("fe_variant", "mfma")
-    # (1b) the headline step at 8x the Infinity Cache: 1024 blocks = 2.1 GB of input resident per step (the default 524 MB is only 2x the
-    #      256 MiB last-level cache; a cyclic sweep should not profit from it, and this leg shows whether it does)
-    try:
-        big = d_iq.repeat(1024 * BLOCK_SAMPLES * 2 // n_bytes) if (1024 * BLOCK_SAMPLES * 2) % n_bytes == 0 else None
-        if big is not None:
-            q = fmrx.Pipeline(0, 1, rf_taps=101, base_audio_taps=101, max_block_bytes=big.numel(), device=torch.cuda.current_device())
-            d_pcm_big = torch.empty(q.n_audio(big.numel()), dtype=torch.int16, device="cuda")
-            ms = event_ms(torch, lambda: q.process_dev(big.data_ptr(), big.numel(), None, d_pcm_big.data_ptr(), wrap=True, stream=stream), 10, warm=5)
-            name, d = leg("mono_1024_blocks", "the headline step with 1024 x 1,024,000-sample blocks (2.1 GB of u8 I/Q, 8 x the 256 MiB Infinity Cache) "
-                          "resident per step: mono_fused_kernel<101,10,101,5>, s16 out", big.numel() // 2, ms, S3_BYTES)
-            legs[name] = d
-            q.close()
-            del q, big, d_pcm_big
-            torch.cuda.empty_cache()
-    except Exception as e:
-        legs["mono_1024_blocks"] = {"error": str(e)}
     # (2) S2: matrix-core front end + discriminator to HBM, then the audio kernel (the two-kernel path)
     pl.set_option("fused_min_audio", 10**12)
     ms = event_ms(torch, step, k)
