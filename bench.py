@@ -7,8 +7,8 @@ GPUs), and the dominant kernel's fraction of the HBM roofline.
 Workload at N=1 = BASELINE.json configs[1]: mode 0 mono, 101-tap front-end FIR + decimate(10) + FM
 discriminator + 101-tap audio FIR + decimate(5) + s16 pack (the reference's output format,
 src/threadMonoOnly.cpp:185-191), synthetic 2.4 MS/s FM I/Q, blocks of 1,024,000 complex samples.  One
-"step" = one pass of the whole chain over a device-resident batch of `--blocks` (default 256)
-consecutive blocks of ONE stream (0.5 GB of u8 I/Q), submitted as one block-parallel call: an offline,
+"step" = one pass of the whole chain over a device-resident batch of `--blocks` (default 1024)
+consecutive blocks of ONE stream (2.1 GB of u8 I/Q: 8 x the 256 MiB Infinity Cache), submitted as one block-parallel call: an offline,
 one-long-stream figure (a live 2.4 MS/s channel delivers 51,200-sample blocks; the per-block latency of
 that regime is reported separately as `small_block`).  The mono chain is a sliding-window map of its
 input, so the block-parallel call equals block-by-block streaming
@@ -283,23 +283,23 @@ def side_legs(torch, fmrx, synth, args, pl, step, d_iq, n_bytes, stream) -> dict
     legs = {}
     n_samples = n_bytes // 2
     k = max(10, min(args.steps, 30))
-    # (0) the headline step at 8x the Infinity Cache: 1024 blocks = 2.1 GB of input resident per step (the default 524 MB is only 2x the
-    #     256 MiB last-level cache; a cyclic sweep should not profit from it, and this leg shows whether it does).  Measured first,
+    # (0) the same step with 256 blocks resident (0.5 GB: BASELINE's minimum, the headline configuration of rounds 1 and 2): a shorter
+    #     call amortises the kernel's ramp-up and tail over fewer tiles per wave (tools/working_set_probe.py: 0.53-0.60 at 256 blocks,
+    #     0.64-0.65 at 1024-2048, pure streaming reads flat at 6.1-6.5 TB/s: no Infinity Cache effect either way).  Measured first,
     #     in the thermal state of the headline (the vector-ALU legs below pull the clocks down for a while)
     try:
-        big = d_iq.repeat(1024 * BLOCK_SAMPLES * 2 // n_bytes) if (1024 * BLOCK_SAMPLES * 2) % n_bytes == 0 else None
-        if big is not None:
-            q = fmrx.Pipeline(0, 1, rf_taps=101, base_audio_taps=101, max_block_bytes=big.numel(), device=torch.cuda.current_device())
-            d_pcm_big = torch.empty(q.n_audio(big.numel()), dtype=torch.int16, device="cuda")
-            ms = event_ms(torch, lambda: q.process_dev(big.data_ptr(), big.numel(), None, d_pcm_big.data_ptr(), wrap=True, stream=stream), 10, warm=5)
-            name, d = leg("mono_1024_blocks", "the headline step with 1024 x 1,024,000-sample blocks (2.1 GB of u8 I/Q, 8 x the 256 MiB Infinity Cache) "
-                          "resident per step: mono_fused_kernel<101,10,101,5>, s16 out", big.numel() // 2, ms, S3_BYTES)
+        nb256 = 256 * BLOCK_SAMPLES * 2
+        if n_bytes >= nb256:
+            q = fmrx.Pipeline(0, 1, rf_taps=101, base_audio_taps=101, max_block_bytes=nb256, device=torch.cuda.current_device())
+            d_pcm_s = torch.empty(q.n_audio(nb256), dtype=torch.int16, device="cuda")
+            ms = event_ms(torch, lambda: q.process_dev(d_iq.data_ptr(), nb256, None, d_pcm_s.data_ptr(), wrap=True, stream=stream), 30, warm=200)
+            name, d = leg("mono_256_blocks", "the headline step with 256 x 1,024,000-sample blocks (0.5 GB) resident per step: "
+                          "mono_fused_kernel<101,10,101,5>, s16 out", nb256 // 2, ms, S3_BYTES)
             legs[name] = d
             q.close()
-            del q, big, d_pcm_big
-            torch.cuda.empty_cache()
+            del q, d_pcm_s
     except Exception as e:
-        legs["mono_1024_blocks"] = {"error": str(e)}
+        legs["mono_256_blocks"] = {"error": str(e)}
     # (1) the same workload through the vector-ALU kernels: the north star's "no MFMA" form (S2 + audio kernel)
     pl.set_option("fe_variant", "valu")
     ms = event_ms(torch, step, k, warm=100)
@@ -569,7 +569,8 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--blocks", type=int, default=256, help="1,024,000-sample blocks resident per step")
+    ap.add_argument("--blocks", type=int, default=1024,
+                    help="1,024,000-sample blocks resident per step (default 1024 = 2.1 GB of u8 I/Q, 8 x the 256 MiB Infinity Cache; BASELINE asks for >= 256)")
     ap.add_argument("--settle-ms", type=float, default=400.0,
                     help="untimed steps run for this long before the warm-up, so that the clocks the chip holds under "
                          "this load are reached (a step is ~0.12 ms; the first ~300 after idle run up to 30 %% slower)")
@@ -676,7 +677,7 @@ def main() -> int:
         if fused and os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if int(tj.get("blocks", -1)) == B and tj.get("output") == "s16":
+                if int(tj.get("blocks", -1)) == B and tj.get("output") == "s16":   # same workload as the counters were collected on
                     if tj.get("lib_src") and tj.get("lib_src") == lib_src:
                         traffic = tj.get("hbm_bytes_per_launch")
                         traffic_source = ("profiles/fe_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on this "
