@@ -312,8 +312,8 @@ FMRX_API int fmrx_pipeline_set_option(fmrx_pipeline *pl, const char *name, long 
 /* many mono channels per device call                                   */
 /* ------------------------------------------------------------------ */
 /* The reference runs one receiver per process (one PARAMS / STATES set, src/project.cpp:460-468); a bank of N
- * receivers is N processes.  fmrx_channels processes the current block of N independent mono channels (modes 0
- * and 1) in ONE kernel launch: what a live multi-channel receiver needs, where one 51 200-sample block per
+ * receivers is N processes.  fmrx_channels processes the current block of N independent channels in one call
+ * (fmrx_channels_create: mono, modes 0 and 1, ONE kernel launch; fmrx_channels_create_ex below: mono or stereo, exact or fast): what a live multi-channel receiver needs, where one 51 200-sample block per
  * channel and launch would leave the chip idle.  A channel's whole carried state is its last ~1 200 input
  * samples, kept as raw bytes in front of its block (csrc/channels.hip); results equal fmrx_pipeline's for the
  * same stream (audio to within float32 summation order, <= 2e-6; PCM +-1 LSB).
@@ -338,6 +338,9 @@ FMRX_API int fmrx_channels_create(fmrx_channels **out, const fmrx_params *p, int
  *                   detector, hardware sine / cosine) walked by one lane per channel -- the error bound of the default
  *                   single-stream stereo path (1e-4 for a stream's first 0.13 s, 0.06 ulp(trigArg(t)) after; mono sum 2e-6)
  *                   at several times the exact bank's rate.
+ * Modes: exact banks cover all four modes (0, 1 integer decimation; 2, 3 the rational resampler convolveBlockResampleFIR,
+ * src/filter.cpp:191-223, in its own evaluation order; a block must then end on an output boundary: n_if * upsamp % decim == 0,
+ * as the reference's own block sizes do); the fast banks cover modes 0 and 1.
  * Outputs: audio_f32 [n_channels][audio_channels][n_audio] (stereo: left, then right), pcm16
  * [n_channels][n_audio][audio_channels] (stereo: interleaved L,R as the writer at src/project.cpp:292-302). */
 FMRX_API int fmrx_channels_create_ex(fmrx_channels **out, const fmrx_params *p, int n_channels, int audio_channels, int exact,

@@ -573,10 +573,73 @@ __global__ __launch_bounds__(64) void chs_out_kernel(const float *__restrict__ d
     }
 }
 
+// ---- the resampling modes (2, 3) behind the PLL, reference order ----------------------------------------------------------
+// RF_STEREO with audio_upsamp > 0 (src/project.cpp:224-231, 262-269): convolveBlockResampleFIR (src/filter.cpp:191-223) on the
+// all-passed discriminator output and on the mixer output.  In stream form: output k reads phase ph = (k D) mod U of the taps and
+// the input samples n_k, n_k - 1, ... with n_k = (k D - ph) / U:  y = sum_j h[ph + j U] x[n_k - j]  (separately rounded products
+// and sums, j ascending), then y += y * U.  A block's outputs restart at phase 0 (the bank accepts blocks with n_if U % D == 0, as
+// the reference's own block sizes are).  The mixer output is materialised here (rows [Hm | n_if], history carried by the finish
+// kernel): the same row serves every output's window.  One thread per (channel, output); the phase rows of the tap table and
+// the windows of neighbouring outputs are L2-resident (this stage is 2 % of the bank's work).
+__global__ void chs_mix_kernel(const float *__restrict__ bpf, const float *__restrict__ nco, long ypitch, const float *__restrict__ nco0,
+                               float *__restrict__ mixer, long mpitch, int hm, long k_lo, long k_hi, long wgs_per_channel)
+{
+    const long c = blockIdx.x / wgs_per_channel;
+    const long k = k_lo + (blockIdx.x % wgs_per_channel) * 256 + threadIdx.x;
+    if (k >= k_hi) return;
+    const float pll = k > 0 ? nco[c * ypitch + k - 1] : nco0[c];               // PLL[k]; PLL[0] = the incoming state's lastOut
+    mixer[c * mpitch + hm + k] = (bpf[c * ypitch + k] * pll) * 2.0f;           // (stereo_filt * PLL) * 2, src/project.cpp:246-248
+}
+
+template <bool STEREO>
+__global__ void chs_resample_exact_kernel(const float *__restrict__ demod, long dpitch, int Hd, const float *__restrict__ mixer, long mpitch,
+                                          int hm, int delay, const float *__restrict__ h, int taps, int decim, int upsamp,
+                                          long wgs_per_channel, float *__restrict__ audio, int16_t *__restrict__ pcm, int wrap, long a_lo,
+                                          long a_hi, long n_out)
+{
+    const long c = blockIdx.x / wgs_per_channel;
+    const long k = a_lo + (blockIdx.x % wgs_per_channel) * 256 + threadIdx.x;
+    if (k >= a_hi) return;
+    const long long m = static_cast<long long>(k) * decim;
+    const int ph = static_cast<int>(m % upsamp);
+    const long n0 = static_cast<long>((m - ph) / upsamp);
+    const float *xm = demod + c * dpitch + Hd + n0 - delay;                    // the all-pass is an index offset
+    const float *xs = STEREO ? mixer + c * mpitch + hm + n0 : nullptr;
+    float am = 0.0f, as = 0.0f;
+    int j = 0;
+    for (int n = ph; n < taps; n += upsamp, j++) {
+        const float hn = h[n];
+        const float pm = hn * xm[-j];
+        am = am + pm;
+        if (STEREO) {
+            const float ps = hn * xs[-j];
+            as = as + ps;
+        }
+    }
+    const float gm = am * static_cast<float>(upsamp);                          // y += y * U  (src/filter.cpp:213)
+    const float mono = am + gm;
+    if (STEREO) {
+        const float gs = as * static_cast<float>(upsamp);
+        const float st = as + gs;
+        const float l = st + mono, r = mono - st;                              // src/project.cpp:278-279
+        if (audio) {
+            audio[c * 2 * n_out + k] = l;
+            audio[c * 2 * n_out + n_out + k] = r;
+        }
+        if (pcm) {
+            pcm[2 * (c * n_out + k)] = pcm_pack_flat(l, wrap);
+            pcm[2 * (c * n_out + k) + 1] = pcm_pack_flat(r, wrap);
+        }
+    } else {
+        if (audio) audio[c * n_out + k] = mono;
+        if (pcm) pcm[c * n_out + k] = pcm_pack_flat(mono, wrap);
+    }
+}
+
 // carried state: per channel, history <- the slot's last hist_bytes bytes; demod history <- the row's last Hd samples
 // (create() rejects blocks shorter than either history, so source and destination never overlap)
 __global__ void chs_finish_kernel(uint8_t *__restrict__ slots, long slot_bytes, long hist_bytes, float *__restrict__ demod,
-                                  long dpitch, int Hd, long n_if)
+                                  long dpitch, int Hd, long n_if, float *__restrict__ mixer, long mpitch, int hm)
 {
     const long c = blockIdx.x;
     uint8_t *slot = slots + c * slot_bytes;
@@ -585,6 +648,10 @@ __global__ void chs_finish_kernel(uint8_t *__restrict__ slots, long slot_bytes, 
     for (long i = threadIdx.x; i < hist_bytes / 16; i += blockDim.x) dst[i] = src[i];
     float *row = demod + c * dpitch;
     for (long i = threadIdx.x; i < Hd; i += blockDim.x) row[i] = row[n_if + i];
+    if (mixer) {                                                   // resampling modes: state_stereofilt = the mixer row's tail
+        float *mr = mixer + c * mpitch;
+        for (long i = threadIdx.x; i < hm; i += blockDim.x) mr[i] = mr[n_if + i];
+    }
 }
 
 __global__ void chs_fill_state_kernel(float *__restrict__ pll, long n)
@@ -612,6 +679,10 @@ struct StereoBank {
     DevBuf<float> demod, carrier, bpf, trig, pll, nco0, mixtail[2];
     DevBuf<int8_t> carrier8;        // fast banks: the sign of the pilot band-pass output, one byte per IF sample
     long cpitch = 0;
+    // resampling modes (2, 3): the plain audio taps and, stereo, the mixer rows [Hm | n_if]
+    bool resample = false;
+    DevBuf<float> h_res, mixer;
+    long mpitch = 0;
     int mix_cur = 0;
     // A stereo call walks the block in chunks on two internal streams: `wide` carries the front end, the band-pass pair and the
     // output stage of every chunk, `lanes` the PLL -- the PLL's few waves (one per 64 channels, a dependent chain each) leave
@@ -682,7 +753,7 @@ int bpf_table_init(StereoBank &b, const float *h_st, const float *h_car)
     return FMRX_OK;
 }
 
-#define CHS_FE_CASES(X) X(101, 10) X(101, 5) X(151, 10) X(151, 5) X(13, 10) X(13, 5)
+#define CHS_FE_CASES(X) X(101, 10) X(101, 5) X(101, 3) X(151, 10) X(151, 5) X(151, 3) X(13, 10) X(13, 5) X(13, 3)
 #define CHS_BPF_CASES(X) X(101) X(151) X(13)
 #define CHS_OUT_CASES(X) X(101, 5) X(101, 6) X(13, 5) X(13, 6)
 
@@ -776,7 +847,8 @@ bool stereo_bank_supported(const fmrx_params &p, int audio_channels)
 #define X(T_) if (p.stereo_taps == T_) st = true;
     CHS_BPF_CASES(X)
 #undef X
-    return fe && au && st && p.audio_upsamp == 0;
+    if (p.audio_upsamp > 0) au = p.audio_taps >= 2 && p.audio_taps <= 65535;   // resampling modes: the batched reference-order resampler takes any taps
+    return fe && au && st;
 }
 
 void stereo_bank_destroy(StereoBank *b) { delete b; }
@@ -784,6 +856,7 @@ void stereo_bank_destroy(StereoBank *b) { delete b; }
 int stereo_bank_create(StereoBank **out, const fmrx_params &p, int n_channels, int audio_channels, int exact, size_t block_bytes)
 {
     if (!exact && audio_channels != 2) return fail(FMRX_EINVAL, "channels: the fast mono bank is fmrx_channels_create's");
+    if (!exact && p.audio_upsamp > 0) return fail(FMRX_EINVAL, "channels: the resampling modes (2, 3) are covered by the exact banks (exact = 1)");
     if (!stereo_bank_supported(p, audio_channels))
         return fail(FMRX_EINVAL, "channels (exact): no reference-order kernels for rf %d/%d, audio %d/%d, stereo %d taps (modes 0 and 1 of the "
                     "reference's tap sets are covered)", p.rf_taps, p.rf_decim, p.audio_taps, p.audio_decim, p.stereo_taps);
@@ -807,15 +880,25 @@ int stereo_bank_create(StereoBank **out, const fmrx_params &p, int n_channels, i
             const size_t need = (static_cast<size_t>(lead) + 15) / 16 * 16;
             if (need > b->hist_bytes) b->hist_bytes = need;
         }
+        b->resample = p.audio_upsamp > 0;
         std::vector<float> ha(p.audio_taps);
-        design_lpf(static_cast<float>(p.if_Fs), 16000.0f, p.audio_taps, ha.data());           // src/project.cpp:321
+        // src/project.cpp:321-323: the resampling modes design the filter at the upsampled rate
+        design_lpf(static_cast<float>(b->resample ? p.if_Fs * p.audio_upsamp : p.if_Fs), 16000.0f, p.audio_taps, ha.data());
+        if (b->resample) {
+            FMRX_TRY(b->h_res.alloc(p.audio_taps));
+            FMRX_HIP(hipMemcpy(b->h_res.p, ha.data(), p.audio_taps * sizeof(float), hipMemcpyHostToDevice));
+        } else {
 #define X(T_, D_) if (p.audio_taps == T_ && p.audio_decim == D_) FMRX_TRY((out_table_init<T_, D_>(*b, ha.data())));
-        CHS_OUT_CASES(X)
+            CHS_OUT_CASES(X)
 #undef X
+        }
         b->n = static_cast<long>(block_bytes / 2);
         b->n_if = b->n / p.rf_decim;
-        b->n_audio = b->n_if / p.audio_decim;
-        b->Ha = p.audio_taps - 1;
+        b->n_audio = b->resample ? b->n_if * p.audio_upsamp / p.audio_decim : b->n_if / p.audio_decim;
+        if (b->resample && (b->n_if * p.audio_upsamp) % p.audio_decim)
+            return fail(FMRX_EINVAL, "channels: n_if * upsamp = %ld is not a multiple of audio_decim %d (a block must end on an output boundary)",
+                        b->n_if * p.audio_upsamp, p.audio_decim);
+        b->Ha = b->resample ? (p.audio_taps - 1) / p.audio_upsamp : p.audio_taps - 1;
         b->St = audio_channels == 2 ? p.stereo_taps : 0;
         b->delay = audio_channels == 2 ? (p.stereo_taps - 1) / 2 : 0;                        // allPass, src/filter.cpp:14-29
         b->Hd = b->Ha + b->delay;
@@ -857,6 +940,11 @@ int stereo_bank_create(StereoBank **out, const fmrx_params &p, int n_channels, i
                 FMRX_TRY(m.alloc(static_cast<size_t>(b->Hm) * N));
                 FMRX_HIP(hipMemset(m.p, 0, m.bytes()));
             }
+            if (b->resample) {
+                b->mpitch = (b->Hm + b->n_if + 16 + 3) / 4 * 4;
+                FMRX_TRY(b->mixer.alloc(b->mpitch * N + 64));
+                FMRX_HIP(hipMemset(b->mixer.p, 0, b->mixer.bytes()));
+            }
             hipLaunchKernelGGL(chs_fill_state_kernel, dim3(static_cast<unsigned>((8 * N + 255) / 256)), dim3(256), 0, nullptr, b->pll.p,
                                static_cast<long>(8 * N));
             CHS_LAUNCH_CHECK("chs_fill_state_kernel");
@@ -895,6 +983,7 @@ int stereo_bank_reset(StereoBank *b, int channel)
         FMRX_HIP(hipMemsetAsync(b->demod.p + c * b->dpitch, 0, b->Hd * sizeof(float), nullptr));
         if (b->audio_channels == 2) {
             for (auto &m : b->mixtail) FMRX_HIP(hipMemsetAsync(m.p + c * b->Hm, 0, b->Hm * sizeof(float), nullptr));
+            if (b->resample) FMRX_HIP(hipMemsetAsync(b->mixer.p + c * b->mpitch, 0, b->Hm * sizeof(float), nullptr));
             hipLaunchKernelGGL(chs_fill_state_kernel, dim3(1), dim3(8), 0, nullptr, b->pll.p + 8 * c, 8L);
         }
     }
@@ -903,6 +992,7 @@ int stereo_bank_reset(StereoBank *b, int channel)
         FMRX_HIP(hipMemsetAsync(b->demod.p, 0, b->demod.bytes(), nullptr));
         if (b->audio_channels == 2) {
             for (auto &m : b->mixtail) FMRX_HIP(hipMemsetAsync(m.p, 0, m.bytes(), nullptr));
+            if (b->resample) FMRX_HIP(hipMemsetAsync(b->mixer.p, 0, b->mixer.bytes(), nullptr));
             const long n8 = 8L * b->n_channels;
             hipLaunchKernelGGL(chs_fill_state_kernel, dim3(static_cast<unsigned>((n8 + 255) / 256)), dim3(256), 0, nullptr, b->pll.p, n8);
         }
@@ -933,14 +1023,28 @@ int stereo_bank_process_dev(StereoBank *b, float *d_audio, int16_t *d_pcm, int w
 #undef X
             return FMRX_EINVAL;
         };
+        // IF samples [.., if_of(a)) are what the audio outputs [.., a) read: a * D in the integer-decimation modes, whole periods
+        // (U outputs <-> D samples) in the resampling modes
+        auto if_of = [&](long a) -> long { return b->resample ? a / p.audio_upsamp * p.audio_decim : a * p.audio_decim; };
         auto out = [&](long a_lo, long a_hi, long g_hi, hipStream_t st) -> int {
+            if (b->resample) {
+                const long k_lo = if_of(a_lo), wm = (g_hi - k_lo + 255) / 256, wr = (a_hi - a_lo + 255) / 256;
+                hipLaunchKernelGGL(chs_mix_kernel, dim3(static_cast<unsigned>(wm * b->n_channels)), dim3(256), 0, st, b->bpf.p, b->trig.p, b->ypitch,
+                                   b->nco0.p, b->mixer.p, b->mpitch, b->Hm, k_lo, g_hi, wm);
+                hipLaunchKernelGGL(chs_resample_exact_kernel<true>, dim3(static_cast<unsigned>(wr * b->n_channels)), dim3(256), 0, st, b->demod.p,
+                                   b->dpitch, b->Hd, b->mixer.p, b->mpitch, b->Hm, b->delay, b->h_res.p, p.audio_taps, p.audio_decim,
+                                   p.audio_upsamp, wr, d_audio, d_pcm, wrap, a_lo, a_hi, b->n_audio);
+                CHS_LAUNCH_CHECK("chs_resample_exact_kernel");
+                return FMRX_OK;
+            }
 #define X(T_, D_) if (p.audio_taps == T_ && p.audio_decim == D_) return launch_out<T_, D_, true>(*b, d_audio, d_pcm, wrap, a_lo, a_hi, g_hi, st);
             CHS_OUT_CASES(X)
 #undef X
             return FMRX_EINVAL;
         };
-        // chunks of whole output workgroups (512 audio samples); chunk c = audio [a_c, a_c+1) = IF [a_c * D, a_c+1 * D)
-        const long unit = 512;
+        // chunks of whole output workgroups (512 audio samples; whole periods of U outputs in the resampling modes);
+        // chunk c = audio [a_c, a_c+1) = IF [if_of(a_c), if_of(a_c+1))
+        const long unit = b->resample ? p.audio_upsamp : 512;
         long per = (b->n_audio + b->max_chunks - 1) / b->max_chunks;
         per = (per + unit - 1) / unit * unit;
         const int K = static_cast<int>((b->n_audio + per - 1) / per);
@@ -963,7 +1067,7 @@ int stereo_bank_process_dev(StereoBank *b, float *d_audio, int16_t *d_pcm, int w
         for (int c = 0; c < K + lag; c++) {
             if (c < K) {
                 const long a_lo = c * per, a_hi = a_lo + per < b->n_audio ? a_lo + per : b->n_audio;
-                const long k_lo = a_lo * p.audio_decim, k_hi = a_hi * p.audio_decim;
+                const long k_lo = if_of(a_lo), k_hi = if_of(a_hi);
                 FMRX_TRY(fe(k_lo, k_hi, sf));
                 if (split) {   // read-after-write: the band-pass pair reads the discriminator rows the front end wrote on its own stream
                     FMRX_HIP(hipEventRecord(b->ev_fe[c], sf));
@@ -989,8 +1093,8 @@ int stereo_bank_process_dev(StereoBank *b, float *d_audio, int16_t *d_pcm, int w
             if (c >= lag) {   // the output stage of an earlier chunk, behind this chunk's band-pass pair on the wide stream
                 const long a_lo = (c - lag) * per, a_hi = a_lo + per < b->n_audio ? a_lo + per : b->n_audio;
                 if (K > 1) FMRX_HIP(hipStreamWaitEvent(sw, b->ev_pll[c - lag], 0));
-                if (b->exact) FMRX_TRY(launch_nco(*b, a_lo * p.audio_decim, a_hi * p.audio_decim, sw));   // fast banks: inside the output stage
-                FMRX_TRY(out(a_lo, a_hi, a_hi * p.audio_decim, sw));
+                if (b->exact) FMRX_TRY(launch_nco(*b, if_of(a_lo), if_of(a_hi), sw));   // fast banks: inside the output stage
+                FMRX_TRY(out(a_lo, a_hi, if_of(a_hi), sw));
             }
         }
         if (K > 1) {
@@ -1000,12 +1104,21 @@ int stereo_bank_process_dev(StereoBank *b, float *d_audio, int16_t *d_pcm, int w
         b->mix_cur ^= 1;
     } else {
         FMRX_TRY(fe(0, b->n_if, s));
+        if (b->resample) {
+            const long wr = (b->n_audio + 255) / 256;
+            hipLaunchKernelGGL(chs_resample_exact_kernel<false>, dim3(static_cast<unsigned>(wr * b->n_channels)), dim3(256), 0, s, b->demod.p,
+                               b->dpitch, b->Hd, nullptr, 0L, 0, b->delay, b->h_res.p, p.audio_taps, p.audio_decim, p.audio_upsamp, wr, d_audio,
+                               d_pcm, wrap, 0L, b->n_audio, b->n_audio);
+            CHS_LAUNCH_CHECK("chs_resample_exact_kernel");
+        } else {
 #define X(T_, D_) if (p.audio_taps == T_ && p.audio_decim == D_) FMRX_TRY((launch_out<T_, D_, false>(*b, d_audio, d_pcm, wrap, 0, b->n_audio, b->n_if, s)));
-        CHS_OUT_CASES(X)
+            CHS_OUT_CASES(X)
 #undef X
+        }
     }
     hipLaunchKernelGGL(chs_finish_kernel, dim3(static_cast<unsigned>(b->n_channels)), dim3(64), 0, s, b->slots.p,
-                       static_cast<long>(b->slot_bytes), static_cast<long>(b->hist_bytes), b->demod.p, b->dpitch, b->Hd, b->n_if);
+                       static_cast<long>(b->slot_bytes), static_cast<long>(b->hist_bytes), b->demod.p, b->dpitch, b->Hd, b->n_if,
+                       b->resample && b->audio_channels == 2 ? b->mixer.p : nullptr, b->mpitch, b->Hm);
     CHS_LAUNCH_CHECK("chs_finish_kernel");
     return FMRX_OK;
 }

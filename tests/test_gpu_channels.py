@@ -31,7 +31,8 @@ def channel_stream(oracle, c, n_samples, rf_Fs):
     return oracle.synth_fm_u8(n_samples, rf_Fs=rf_Fs, seed=0x3D74 + c, start=0 if c == 0 else 7919 * c)
 
 
-@pytest.mark.parametrize("mode,taps", [(0, (101, 101, 101)), (1, (101, 101, 101)), (0, (151, 101, 151)), (0, (13, 13, 13))])
+@pytest.mark.parametrize("mode,taps", [(0, (101, 101, 101)), (1, (101, 101, 101)), (0, (151, 101, 151)), (0, (13, 13, 13)),
+                                       (2, (101, 101, 101)), (3, (101, 101, 101)), (2, (13, 13, 13))])
 def test_stereo_bank_exact(fmrx, oracle, mode, taps):
     """Five stereo receivers, four reference-size blocks each, every intermediate of every channel against the oracle
     streaming that channel alone: discriminator output, both band-pass outputs, NCO, left, right -- all bit for bit;
@@ -41,7 +42,7 @@ def test_stereo_bank_exact(fmrx, oracle, mode, taps):
     streams = [channel_stream(oracle, c, bb // 2 * (nblk + 2), p.rf_Fs) for c in range(N)]
     ch = fmrx.Channels(mode, N, rf_taps=taps[0], base_audio_taps=taps[1], stereo_taps=taps[2], audio_channels=2, exact=True)
     refs = [oracle.pipeline(mode, 2, *taps) for _ in range(N)]
-    assert ch.n_audio == 1024
+    assert ch.n_audio == {0: 1024, 1: 1024, 2: 1029, 3: 3087}[mode]     # the reference's blocks: src/project.cpp:55-57
 
     def check(b, channels):
         iq = np.stack([st[b * bb:(b + 1) * bb] for st in streams])
@@ -68,7 +69,7 @@ def test_stereo_bank_exact(fmrx, oracle, mode, taps):
 
 def test_mono_bank_exact(fmrx, oracle):
     """The mono bank in the reference's evaluation order: audio bit for bit (the specialised mono bank promises 2e-6)."""
-    for mode in (0, 1):
+    for mode in (0, 1, 2, 3):
         p = oracle.mode_params(mode, 101, 101, 101)
         N, nblk, bb = 3, 3, p.block_bytes
         streams = [channel_stream(oracle, c, bb // 2 * nblk, p.rf_Fs) for c in range(N)]
@@ -101,7 +102,9 @@ def test_bank_other_block_sizes(fmrx, oracle):
     with pytest.raises(fmrx.FmrxError):
         fmrx.Channels(0, 4, audio_channels=2, exact=True, block_bytes=1600)      # shorter than the history a channel carries
     with pytest.raises(fmrx.FmrxError):
-        fmrx.Channels(2, 4, audio_channels=2, exact=True)                        # resampling modes: not in the bank
+        fmrx.Channels(2, 4, audio_channels=2, exact=False)                       # resampling modes: exact banks only
+    with pytest.raises(fmrx.FmrxError):
+        fmrx.Channels(2, 4, audio_channels=2, exact=True, block_bytes=16160)     # 808 IF samples: a block must end on an output boundary (n_if * U % D == 0)
 
 
 def test_stereo_bank_fast_error_envelope(fmrx, oracle):
