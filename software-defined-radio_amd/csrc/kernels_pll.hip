@@ -192,23 +192,39 @@ __device__ __forceinline__ void store_state(float *st, const PllState &s)
 }
 
 // ---- serial form: one lane walks the block -------------------------------------------------
+// One wave: all 64 lanes move the samples (64 at a time, coalesced, through LDS), lane 0 walks the recurrence on LDS only --
+// no memory access sits between two steps of the chain.  kExact runs the branch-free forms of glibc's functions where they are
+// defined (pll_step_exact_flat: same values), the general ones elsewhere.
 template <int MATH>
-__global__ void pll_serial_kernel(const float *__restrict__ in, size_t n, float *__restrict__ out, float *__restrict__ state,
-                                  PllCoef c)
+__global__ __launch_bounds__(64) void pll_serial_kernel(const float *__restrict__ in, size_t n, float *__restrict__ out, float *__restrict__ state,
+                                                        PllCoef c)
 {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    __shared__ uint32_t w24[24];
+    __shared__ float lin[64], lout[64];
+    if (blockIdx.x != 0) return;
+    const int lane = threadIdx.x;
+    if (lane < 24) w24[lane] = glibc235::inv_pio4(lane);
     PllState s = load_state(state);
-    out[0] = s.last;
-    if (n == 0) return;
-    float vn = in[0];                                     // next sample, fetched one step ahead of the chain
-    for (size_t k = 0; k < n; k++) {
-        const float v = vn;
-        vn = in[k + 1 < n ? k + 1 : k];
-        pll_step<MATH>(s, v, c);
-        out[k + 1] = s.last;                              // the raw trigArg, see nco_out_kernel
+    if (lane == 0) out[0] = s.last;
+    for (size_t b = 0; b < n; b += 64) {
+        const size_t m = n - b < 64 ? n - b : 64;
+        __syncthreads();                                      // the previous batch's results have left LDS
+        if (static_cast<size_t>(lane) < m) lin[lane] = in[b + lane];
+        __syncthreads();
+        if (lane == 0) {
+            for (size_t k = 0; k < m; k++) {
+                if (MATH == kExact) pll_step_exact_flat(s, lin[k], c, w24);
+                else pll_step<MATH>(s, lin[k], c);
+                lout[k] = s.last;                             // the raw trigArg, see nco_out_kernel
+            }
+        }
+        __syncthreads();
+        if (static_cast<size_t>(lane) < m) out[b + lane + 1] = lout[lane];
     }
-    finish_state<MATH>(s, c);
-    store_state(state, s);
+    if (lane == 0) {
+        finish_state<MATH>(s, c);
+        store_state(state, s);
+    }
 }
 
 // second pass, in parallel: out[k] = cosf(trigArg[k]*ncoScale + phaseAdjust) for k = 1..n, in place
