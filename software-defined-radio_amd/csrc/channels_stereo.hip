@@ -692,10 +692,11 @@ struct StereoBank {
     int max_chunks = kMaxChunks;
     hipStream_t wide = nullptr, lanes = nullptr;
     hipStream_t front = nullptr;    // fast banks: the HBM-bound front end runs on its own stream, next to the vector-ALU-bound kernels
+    hipStream_t post = nullptr;     // fast banks, option bank_streams = 4: the output stage on a stream of its own too
     hipEvent_t ev_bpf[kMaxChunks] = {}, ev_pll[kMaxChunks] = {}, ev_fe[kMaxChunks] = {}, ev_fork = nullptr, ev_join = nullptr;
     ~StereoBank()
     {
-        for (hipStream_t st : {wide, lanes, front})
+        for (hipStream_t st : {wide, lanes, front, post})
             if (st) {
                 (void)hipStreamSynchronize(st);
                 (void)hipStreamDestroy(st);
@@ -951,6 +952,7 @@ int stereo_bank_create(StereoBank **out, const fmrx_params &p, int n_channels, i
             FMRX_HIP(hipStreamCreateWithFlags(&b->wide, hipStreamNonBlocking));
             FMRX_HIP(hipStreamCreateWithFlags(&b->lanes, hipStreamNonBlocking));
             FMRX_HIP(hipStreamCreateWithFlags(&b->front, hipStreamNonBlocking));
+            FMRX_HIP(hipStreamCreateWithFlags(&b->post, hipStreamNonBlocking));
             for (auto &e : b->ev_fe) FMRX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             for (auto &e : b->ev_bpf) FMRX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             for (auto &e : b->ev_pll) FMRX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1053,11 +1055,16 @@ int stereo_bank_process_dev(StereoBank *b, float *d_audio, int16_t *d_pcm, int w
         // vector ALUs: on two streams they run side by side (option bank_streams = 2: everything but the PLL on one stream)
         const bool split = K > 1 && !b->exact && b->opt.bank_streams >= 3;
         hipStream_t sf = split ? b->front : sw;
+        // bank_streams = 4: the output stage (bound by the latency of its staging, not by the vector ALUs) on a fourth stream, next to
+        // the band-pass pair instead of behind it
+        const bool split_out = split && b->opt.bank_streams >= 4;
+        hipStream_t so = split_out ? b->post : sw;
         if (K > 1) {   // whatever the caller's stream did before the call (loading the slots, reading the last output) comes first
             FMRX_HIP(hipEventRecord(b->ev_fork, s));
             FMRX_HIP(hipStreamWaitEvent(sw, b->ev_fork, 0));
             FMRX_HIP(hipStreamWaitEvent(sl, b->ev_fork, 0));
             if (split) FMRX_HIP(hipStreamWaitEvent(sf, b->ev_fork, 0));
+            if (split_out) FMRX_HIP(hipStreamWaitEvent(so, b->ev_fork, 0));
         }
         // The output stage of chunk c follows the band-pass pair of chunk c + lag on the wide stream.  Exact banks: lag 1 (the PLL is
         // the longest stage; nothing on the wide stream is waited for).  Fast banks: lag 2 -- the PLL of chunk c starts when its
@@ -1092,13 +1099,13 @@ int stereo_bank_process_dev(StereoBank *b, float *d_audio, int16_t *d_pcm, int w
             }
             if (c >= lag) {   // the output stage of an earlier chunk, behind this chunk's band-pass pair on the wide stream
                 const long a_lo = (c - lag) * per, a_hi = a_lo + per < b->n_audio ? a_lo + per : b->n_audio;
-                if (K > 1) FMRX_HIP(hipStreamWaitEvent(sw, b->ev_pll[c - lag], 0));
-                if (b->exact) FMRX_TRY(launch_nco(*b, if_of(a_lo), if_of(a_hi), sw));   // fast banks: inside the output stage
-                FMRX_TRY(out(a_lo, a_hi, if_of(a_hi), sw));
+                if (K > 1) FMRX_HIP(hipStreamWaitEvent(so, b->ev_pll[c - lag], 0));   // (the PLL followed this chunk's band-pass pair: both are done)
+                if (b->exact) FMRX_TRY(launch_nco(*b, if_of(a_lo), if_of(a_hi), so));   // fast banks: inside the output stage
+                FMRX_TRY(out(a_lo, a_hi, if_of(a_hi), so));
             }
         }
         if (K > 1) {
-            FMRX_HIP(hipEventRecord(b->ev_join, sw));
+            FMRX_HIP(hipEventRecord(b->ev_join, so));               // the last output stage follows everything else of the call
             FMRX_HIP(hipStreamWaitEvent(s, b->ev_join, 0));
         }
         b->mix_cur ^= 1;
