@@ -1071,11 +1071,19 @@ int stereo_bank_process_dev(StereoBank *b, float *d_audio, int16_t *d_pcm, int w
         // band-pass pair ends and takes longer than the next chunk's band-pass pair: with lag 1 the wide stream idled a third
         // of the time waiting for it.
         const int lag = (b->exact || K < 3) ? 1 : 2;
+        // the front end works in whole tiles of its own (63 x 8 outputs per wave; 120 per matrix-core tile): its share of a chunk
+        // ends on the first tile boundary at or behind the chunk's end, so that no chunk pays for a partly filled last tile
+        // (2560-sample chunks are 5.08 tiles of 504: 15 % of the exact front end's work was computed and thrown away)
+        const long fe_tile = b->exact ? 63 * kR : 120;
+        long fe_done = 0;
         for (int c = 0; c < K + lag; c++) {
             if (c < K) {
                 const long a_lo = c * per, a_hi = a_lo + per < b->n_audio ? a_lo + per : b->n_audio;
                 const long k_lo = if_of(a_lo), k_hi = if_of(a_hi);
-                FMRX_TRY(fe(k_lo, k_hi, sf));
+                long fe_hi = (k_hi + fe_tile - 1) / fe_tile * fe_tile;
+                if (fe_hi > b->n_if || c == K - 1) fe_hi = b->n_if;
+                if (fe_hi > fe_done) FMRX_TRY(fe(fe_done, fe_hi, sf));
+                fe_done = fe_hi;
                 if (split) {   // read-after-write: the band-pass pair reads the discriminator rows the front end wrote on its own stream
                     FMRX_HIP(hipEventRecord(b->ev_fe[c], sf));
                     FMRX_HIP(hipStreamWaitEvent(sw, b->ev_fe[c], 0));

@@ -388,5 +388,44 @@ FMRX_HD void sincosf_large_flat(float y, const uint32_t *w24, float *sn, float *
     *cs = (rn & 1) ? sp : cp;
 }
 
+// 120 <= |y| < 2^25 (the PLL's trigArg from a stream's 240th sample to its 67 millionth): reduce_large then only asks for three
+// of 4/pi's 24 windows per operand, so the table look-up (a lane-varying LDS read on the recurrence's dependent chain) becomes two
+// selects between constants.  Same integers, same floats as sincosf_large_flat.
+FMRX_HD bool sincosf_mid_ok(float y)
+{
+    const uint32_t a = f2u(y) & 0x7fffffffu;
+    return a >= 0x42f00000u && a < 0x4c000000u;
+}
+
+FMRX_HD void sincosf_mid_flat(float y, float *sn, float *cs)
+{
+    const uint32_t xi = f2u(y);
+    const int idx = static_cast<int>((xi >> 26) & 15);         // 0, 1 or 2 here
+    const int shift = static_cast<int>((xi >> 23) & 7);
+    uint32_t m = (xi & 0xffffffu) | 0x800000u;
+    m <<= shift;
+    // inv_pio4(0..2), (4..6), (8..10): windows of 00 00 00 a2 f9 83 6e 4e 44 15 29 fc 27 57 ...
+    const uint32_t w0 = idx == 0 ? 0x000000a2u : (idx == 1 ? 0x0000a2f9u : 0x00a2f983u);
+    const uint32_t w4 = idx == 0 ? 0xf9836e4eu : (idx == 1 ? 0x836e4e44u : 0x6e4e4415u);
+    const uint32_t w8 = idx == 0 ? 0x441529fcu : (idx == 1 ? 0x1529fc27u : 0x29fc2757u);
+    uint64_t res0 = static_cast<uint32_t>(m * w0);
+    const uint64_t res1 = static_cast<uint64_t>(m) * w4;
+    const uint64_t res2 = static_cast<uint64_t>(m) * w8;
+    res0 = (res2 >> 32) | (res0 << 32);
+    res0 += res1;
+    const uint64_t n = (res0 + (1ull << 61)) >> 62;
+    res0 -= n << 62;
+    const double rx = static_cast<double>(static_cast<int64_t>(res0)) * kPi63;
+    const int rn = static_cast<int>(n);
+    const int mq = rn + static_cast<int>(xi >> 31);
+    const double x2 = rx * rx;
+    const double xs = ((mq + 1) & 2) ? -rx : rx;
+    const float sp = sin_poly(xs, x2);
+    const float cp0 = cos_poly(x2);
+    const float cp = (mq & 2) ? -cp0 : cp0;
+    *sn = (rn & 1) ? cp : sp;
+    *cs = (rn & 1) ? sp : cp;
+}
+
 }  // namespace glibc235
 }  // namespace fmrx

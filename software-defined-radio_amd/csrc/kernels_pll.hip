@@ -135,7 +135,10 @@ __device__ __forceinline__ void pll_step_exact_flat(PllState &s, float v, const 
     s.phase = (s.phase + pe) + s.integ;
     s.off += 1;
     const float trigArg = static_cast<float>(c.w * static_cast<double>(s.off) + static_cast<double>(s.phase));
-    if (__builtin_expect(!__any(!glibc235::sincosf_large_ok(trigArg)), 1)) glibc235::sincosf_large_flat(trigArg, w24, &s.fbQ, &s.fbI);
+    // 120 <= trigArg < 2^25 (a stream's samples 240 .. 6.7e7): the table look-up of the reduction is two selects between constants;
+    // beyond, the LDS table; below 120 (or not finite), the general function
+    if (__builtin_expect(!__any(!glibc235::sincosf_mid_ok(trigArg)), 1)) glibc235::sincosf_mid_flat(trigArg, &s.fbQ, &s.fbI);
+    else if (!__any(!glibc235::sincosf_large_ok(trigArg))) glibc235::sincosf_large_flat(trigArg, w24, &s.fbQ, &s.fbI);
     else glibc235::sincosf_glibc(trigArg, &s.fbQ, &s.fbI);
     s.last = trigArg;
 }
@@ -863,7 +866,8 @@ __global__ void libm_eval_kernel(int fn, const float *__restrict__ a, const floa
         out[i] = glibc235::atan2f_flat_ok(a[i], b[i]) ? glibc235::atan2f_flat(a[i], b[i]) : glibc235::atan2f_glibc(a[i], b[i]);
     } else {
         float sn, cs;
-        if (glibc235::sincosf_large_ok(a[i])) glibc235::sincosf_large_flat(a[i], w24, &sn, &cs);
+        if (glibc235::sincosf_mid_ok(a[i])) glibc235::sincosf_mid_flat(a[i], &sn, &cs);
+        else if (glibc235::sincosf_large_ok(a[i])) glibc235::sincosf_large_flat(a[i], w24, &sn, &cs);
         else glibc235::sincosf_glibc(a[i], &sn, &cs);
         out[i] = fn == 3 ? sn : cs;
     }

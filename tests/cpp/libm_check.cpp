@@ -59,6 +59,12 @@ int main(int argc, char **argv)
                         if (!same(c, wc)) { bad_c++; report("cosf (flat)", x, 0, c, wc); }
                         nflat++;
                     }
+                    if (sincosf_mid_ok(x)) {                 // and the form with the table look-up folded into selects
+                        sincosf_mid_flat(x, &s, &c);
+                        if (!same(s, ws)) { bad_s++; report("sinf (mid)", x, 0, s, ws); }
+                        if (!same(c, wc)) { bad_c++; report("cosf (mid)", x, 0, c, wc); }
+                        nflat++;
+                    }
                 }
                 flat_sc += nflat;
             });
