@@ -90,6 +90,10 @@ FMRX_API int fmrx_set_device(int device);
  *   "demod"            0 (default) = the C++ reference's discriminator fmDemod (src/filter.cpp:248-266); 1 = the Python model's
  *                      arctangent demodulator fmDemodArctan (model/fmSupportLib.py:502-531, float64 atan2 + unwrap): the pipeline
  *                      then runs its unfused kernels (front end -> IF stream -> arctan -> audio / stereo stages)
+ *   "bank_streams"     fast stereo banks (fmrx_channels_create_ex, exact = 0): internal streams of a call: 3 (default) = front end |
+ *                      band-pass pair + output stage | PLL lanes; 2 = the front end with the other wide kernels; 4 = the output stage apart too
+ *   "bank_fused"       fast stereo banks: 1 = front end + band-pass pair in ONE kernel (f32 matrix cores; measured slower: default 0)
+ *   "bank_fe_wgs", "bank_fe_wgs_fused"        workgroups per CU of the bank's matrix-core front end (1) / of the fused kernel (2)
  *   "fused_tune", "fe_mfma_tune"              ablation kernels (timing only, WRONG results): FMRX_EINVAL unless the
  *                                            library was built with -DFMRX_TUNING (make TUNING=1; never shipped) */
 FMRX_API int fmrx_set_option(const char *name, long value);

@@ -62,6 +62,8 @@ bool option_ref(Options &o, const char *name, long **as_long, int **as_int)
     else if (n == "demod") *as_int = &o.demod;
     else if (n == "bank_streams") *as_int = &o.bank_streams;
     else if (n == "bank_fe_wgs") *as_int = &o.bank_fe_wgs;
+    else if (n == "bank_fused") *as_int = &o.bank_fused;
+    else if (n == "bank_fe_wgs_fused") *as_int = &o.bank_fe_wgs_fused;
     else if (n == "resample_chains") *as_int = &o.resample_chains;
     else if (n == "overlap_calls") *as_int = &o.overlap_calls;
     else if (n == "fused_tune") *as_int = &o.fused_tune;
@@ -90,6 +92,7 @@ Options &default_options()
         if (const char *e = std::getenv("FMRX_PLL_MODE")) d.pll_mode = std::atoi(e);
         if (const char *e = std::getenv("FMRX_BANK_STREAMS")) d.bank_streams = std::atoi(e);
         if (const char *e = std::getenv("FMRX_BANK_FE_WGS")) d.bank_fe_wgs = std::atoi(e);
+        if (const char *e = std::getenv("FMRX_BANK_FUSED")) d.bank_fused = std::atoi(e);
         if (const char *e = std::getenv("FMRX_DEMOD")) d.demod = std::strcmp(e, "arctan") == 0 ? 1 : std::atoi(e);
 #ifdef FMRX_TUNING
         if (const char *e = std::getenv("FMRX_FUSED_TUNE")) d.fused_tune = std::atoi(e);

@@ -675,6 +675,8 @@ struct StereoBank {
     DevBuf<uint8_t> slots;
     DevBuf<float> fe_table, bpf_table, out_table;
     FePlan fe;                      // fast banks: the matrix-core front end's tap image
+    DevBuf<float> st_img, car_img;  // fast banks: the band-pass filters' Toeplitz images for the f32 matrix cores (fe_bpf_bank_kernel)
+    bool fused_front = false;       // front end + band-pass pair in one kernel
     Options opt;
     DevBuf<float> demod, carrier, bpf, trig, pll, nco0, mixtail[2];
     DevBuf<int8_t> carrier8;        // fast banks: the sign of the pilot band-pass output, one byte per IF sample
@@ -925,6 +927,10 @@ int stereo_bank_create(StereoBank **out, const fmrx_params &p, int n_channels, i
 #define X(T_) if (p.stereo_taps == T_) FMRX_TRY(bpf_table_init<T_>(*b, hs.data(), hc.data()));
             CHS_BPF_CASES(X)
 #undef X
+            if (!b->exact && !b->resample && fe_bpf_bank_available(b->fe, p.stereo_taps)) {
+                FMRX_TRY(fe_bpf_tables_init(b->st_img, b->car_img, hs.data(), hc.data(), p.stereo_taps));
+                b->fused_front = true;
+            }
             if (b->exact) {
                 FMRX_TRY(b->carrier.alloc(b->ypitch * N + 64));
                 FMRX_HIP(hipMemset(b->carrier.p, 0, b->carrier.bytes()));
@@ -1080,18 +1086,31 @@ int stereo_bank_process_dev(StereoBank *b, float *d_audio, int16_t *d_pcm, int w
             if (c < K) {
                 const long a_lo = c * per, a_hi = a_lo + per < b->n_audio ? a_lo + per : b->n_audio;
                 const long k_lo = if_of(a_lo), k_hi = if_of(a_hi);
-                long fe_hi = (k_hi + fe_tile - 1) / fe_tile * fe_tile;
-                if (fe_hi > b->n_if || c == K - 1) fe_hi = b->n_if;
-                if (fe_hi > fe_done) FMRX_TRY(fe(fe_done, fe_hi, sf));
-                fe_done = fe_hi;
-                if (split) {   // read-after-write: the band-pass pair reads the discriminator rows the front end wrote on its own stream
-                    FMRX_HIP(hipEventRecord(b->ev_fe[c], sf));
-                    FMRX_HIP(hipStreamWaitEvent(sw, b->ev_fe[c], 0));
-                }
-                FMRX_TRY(bpf(k_lo, k_hi, sw));
-                if (K > 1) {
-                    FMRX_HIP(hipEventRecord(b->ev_bpf[c], sw));
-                    FMRX_HIP(hipStreamWaitEvent(sl, b->ev_bpf[c], 0));
+                const bool fused = b->fused_front && b->opt.bank_fused != 0;
+                if (fused) {
+                    // fast banks: front end + band-pass pair in ONE kernel (int8 + f32 matrix cores), on the front stream
+                    FMRX_TRY(fe_bpf_bank_launch(b->fe, p.stereo_taps, b->st_img.p, b->car_img.p, b->slots.p, static_cast<long>(b->slots.n),
+                                                static_cast<long>(b->slot_bytes), static_cast<long>(b->hist_bytes), b->n_channels, k_lo, k_hi,
+                                                b->demod.p, b->dpitch, b->Hd, b->bpf.p, b->ypitch, b->carrier8.p, b->cpitch,
+                                                b->opt.bank_fe_wgs_fused, sf));
+                    if (K > 1) {   // read-after-write: the PLL's lanes read the sign bytes this kernel wrote
+                        FMRX_HIP(hipEventRecord(b->ev_bpf[c], sf));
+                        FMRX_HIP(hipStreamWaitEvent(sl, b->ev_bpf[c], 0));
+                    }
+                } else {
+                    long fe_hi = (k_hi + fe_tile - 1) / fe_tile * fe_tile;
+                    if (fe_hi > b->n_if || c == K - 1) fe_hi = b->n_if;
+                    if (fe_hi > fe_done) FMRX_TRY(fe(fe_done, fe_hi, sf));
+                    fe_done = fe_hi;
+                    if (split) {   // read-after-write: the band-pass pair reads the discriminator rows the front end wrote on its own stream
+                        FMRX_HIP(hipEventRecord(b->ev_fe[c], sf));
+                        FMRX_HIP(hipStreamWaitEvent(sw, b->ev_fe[c], 0));
+                    }
+                    FMRX_TRY(bpf(k_lo, k_hi, sw));
+                    if (K > 1) {
+                        FMRX_HIP(hipEventRecord(b->ev_bpf[c], sw));
+                        FMRX_HIP(hipStreamWaitEvent(sl, b->ev_bpf[c], 0));
+                    }
                 }
                 // fmPLL(carrier_filt, 19 kHz, if_Fs, ncoScale 2, phaseAdjust 0, normBandwidth 0.01): src/project.cpp:237
                 if (b->exact)

@@ -64,6 +64,9 @@ struct Options {
                                    //   (default); 1 = serial, fast math; 2 = serial, glibc math (the cause-by-cause variants of DESIGN 2)
     int bank_streams = 3;          // "bank_streams" / FMRX_BANK_STREAMS: fast stereo banks: 3 = front end | band-pass pair + output stage | PLL lanes on
                                    //   three internal streams (default), 2 = the front end on the same stream as the other wide kernels
+    int bank_fused = 0;            // "bank_fused" / FMRX_BANK_FUSED: fast stereo banks: 1 = front end + band-pass pair in one kernel (int8 + f32 matrix
+                                   //   cores: measured slower, kernels_fe_mfma.hip), 0 = two kernels (matrix-core front end, vector-ALU band-pass pair; default)
+    int bank_fe_wgs_fused = 2;     // "bank_fe_wgs_fused": workgroups per CU of that fused kernel
     int bank_fe_wgs = 1;           // "bank_fe_wgs" / FMRX_BANK_FE_WGS: workgroups per CU of the bank's matrix-core front end (1 leaves registers and
                                    //   LDS for the kernels that run next to it; 0 = as many as fit)
     int demod = 0;                 // "demod" / FMRX_DEMOD: 0 = the C++ reference's discriminator (fmDemod, src/filter.cpp:248-266; default),
@@ -136,6 +139,13 @@ int fe_mfma_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, cons
 int fe_mfma_bank_lead(const FePlan &pl);   // bytes of the stream a row needs in front of its block
 int fe_mfma_bank_launch(const FePlan &pl, const uint8_t *d_slots, long total_bytes, long in_pitch, long block_off, int n_channels,
                         long k_lo, long k_hi, float *d_demod, long out_pitch, long out_off, int wgs_per_cu_cap, hipStream_t stream);
+// front end + both stereo band-pass filters in one kernel over the bank's rows (int8 + f32 matrix cores): kernels_fe_mfma.hip
+bool fe_bpf_bank_available(const FePlan &pl, int stereo_taps);
+int fe_bpf_tables_init(DevBuf<float> &st_img, DevBuf<float> &car_img, const float *h_st, const float *h_car, int taps);
+int fe_bpf_bank_launch(const FePlan &pl, int stereo_taps, const float *d_st_img, const float *d_car_img, const uint8_t *d_slots,
+                       long total_bytes, long in_pitch, long block_off, int n_channels, long k_lo, long k_hi, float *d_demod,
+                       long out_pitch, long out_off, float *d_bpf, long bpf_pitch, int8_t *d_car8, long car_pitch, int wgs_per_cu_cap,
+                       hipStream_t stream);
 // d_hist: hist_bytes bytes whose LAST 2*(taps-1) hold the previous samples.
 // Writes n_samples/decim float2 (I,Q) to d_if.
 int fe_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, const uint8_t *d_hist, float *d_if,

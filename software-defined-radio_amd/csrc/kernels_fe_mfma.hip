@@ -470,6 +470,180 @@ __global__ __launch_bounds__(256, 2) void fe_mfma_bank_kernel(const uint8_t *__r
     }
 }
 
+// ---- front end + BOTH stereo band-pass filters over a bank of receivers, one kernel --------------------------------
+// The fast stereo bank's first two stages in one pass over HBM: the int8 front end above, its discriminator output kept in LDS
+// as well as written to its row, and the two convolveBlockFIR calls of RF_STEREO (src/project.cpp:202, 207 -> src/filter.cpp:133-154)
+// on the f32 matrix cores -- the audio FIR's scheme of the fused mono kernel with decimation 1: rows = 16 consecutive
+// outputs, columns = 15 such groups (a batch = two front-end tiles = 240 outputs), K = the TS-1+15+1 samples a column touches,
+// A = the taps, Toeplitz-shifted per row (audio_mfma_build_table(h, TS, 1)), one image per filter, resident in registers.
+// 2 x 32 MFMAs per batch next to the two tiles' 36 int8 ones, and the discriminator row is not read back by a second kernel.
+// MEASURED, AND NOT THE DEFAULT (option bank_fused = 1 selects it): 435-492 us per 2560 IF samples x 16 384 channels against 206-260 +
+// 167-172 us for the two separate kernels -- the f32 matrix cores have the vector ALUs' own peak (v_mfma_f32_16x16x4_f32: 1024
+// multiply-adds in 32 cycles = a packed fma's rate; the 16 % the Toeplitz shape wastes on top), so moving the band-pass pair there buys
+// only what overlaps, and a wave that multiplies its batch is not streaming.  Kept: it is correct (same envelope test), and it is
+// the measurement behind DESIGN.md 4.7's statement of what the fast bank would need.
+// Work: persistent waves; a wave's items are (channel, tile) pairs, channel = wave, wave + n_waves, ...; the tiles of a channel's
+// row in order (the band-pass filters need the 100 samples in front: the row's history at tile 0, the previous batch after
+// that).  LDS per wave: the DMA ring + 368 floats [128 history | 240 batch].  Outputs: discriminator row (f32), 22-54 kHz
+// band-pass row (f32), the SIGN of the pilot band-pass output as one byte per sample (what the fast PLL reads, kernels_pll.hip).
+template <int T, int D, int TS>
+__global__ __launch_bounds__(256, 2) void fe_bpf_bank_kernel(const uint8_t *__restrict__ x, long n_bytes, const i4 *__restrict__ a_img,
+                                                              float scale_lo, const float *__restrict__ st_img,
+                                                              const float *__restrict__ car_img, float *__restrict__ demod,
+                                                              float *__restrict__ bpf, long bpf_pitch, long bpf_off,
+                                                              int8_t *__restrict__ car8, long car_pitch, long car_off, FeBankGeom bk,
+                                                              int n_channels)
+{
+    using C = MfCfg<T, D, 0>;
+    constexpr int AK = ((TS - 1) + 15 + 1 + 15) / 16 * 4;     // audio_mfma_ksteps(TS, 1)
+    constexpr int HB = 128, BATCH = 2 * C::TILE_OUT, BUF = HB + BATCH + 32;   // (+32: the unused 16th column's window reaches past the batch)
+    static_assert(TS - 1 <= HB && (HB - (TS - 1)) % 4 == 0 && C::TILE_OUT == 120, "column 0's window starts TS-1 samples in front of the batch, 16-byte aligned");
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    uint8_t *ring = lds_raw + wave * (C::RING + BUF * 4);
+    float *buf = reinterpret_cast<float *>(ring + C::RING);
+    const int n_waves = static_cast<int>(gridDim.x) * 4;
+    const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * 4 + wave);
+    const int tpc = bk.tiles_per_row;
+    const int my_ch = wid < n_channels ? (n_channels - wid + n_waves - 1) / n_waves : 0;   // channels of this wave
+    const long n_items = static_cast<long>(my_ch) * tpc;
+    if (n_items == 0) return;
+    i4 a[C::KSTEPS][C::NDIG];
+#pragma unroll
+    for (int j = 0; j < C::KSTEPS; j++)
+#pragma unroll
+        for (int d = 0; d < C::NDIG; d++) a[j][d] = a_img[(j * C::NDIG + d) * 64 + lane];
+    float ast[AK], acar[AK];
+#pragma unroll
+    for (int j = 0; j < AK; j++) {
+        ast[j] = st_img[j * 64 + lane];
+        acar[j] = car_img[j * 64 + lane];
+    }
+    for (int i = lane; i < BUF; i += 64) buf[i] = 0.0f;       // finite everywhere: zero taps times stale NaN bits would not be zero
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < C::KSTEPS; j++)
+#pragma unroll
+        for (int d = 0; d < C::NDIG; d++) asm volatile("" : "+v"(a[j][d]));
+#pragma unroll
+    for (int j = 0; j < AK; j++) asm volatile("" : "+v"(ast[j]), "+v"(acar[j]));
+    auto dma = [&](long q, int rs) {
+        const int cq = static_cast<int>(q / tpc), t = static_cast<int>(q - static_cast<long>(cq) * tpc);
+        const long c = wid + static_cast<long>(cq) * n_waves;
+        const long s0 = c * bk.in_pitch + bk.in_off + static_cast<long>(t) * C::STRIDE_BYTES - C::LEAD;
+        dma_window<C::NPF, C::REM_LANES, 0>(x, x, n_bytes, s0, ring + rs * C::SLOT, lane);
+    };
+#pragma unroll
+    for (int k = 0; k < C::P; k++)
+        if (k < n_items) dma(k, k);
+    const int col = lane & 15, g = lane >> 4;
+    const int lane_off = C::COL_BYTES * col + 16 * g;
+    const float scale_hi = scale_lo * 65536.0f;
+    const int src_lane = lane >= 16 ? lane - 16 : lane + 47;
+    int slot = 0, fill = C::P;
+    int t = 0;                                                // tile inside the channel's row
+    long c = wid;                                             // channel
+    for (long q = 0; q < n_items; q++) {
+        const bool steady = q + C::P < n_items;
+        // tile 0 of a row: the 128 discriminator samples in front of this launch's share of the row (the row's carried history, or
+        // what an earlier launch wrote): plain loads, once per channel, requested in front of this iteration's DMA so that the wait
+        // for them does not include it
+        float h0 = 0.0f, h1 = 0.0f;
+        if (t == 0) {
+            const float *hp = demod + c * bk.out_pitch + bk.out_off - HB;
+            h0 = hp[lane];
+            h1 = hp[64 + lane];
+        }
+        if (steady) dma(q + C::P, fill);
+        if (t == 0) {
+            buf[lane] = h0;
+            buf[64 + lane] = h1;
+        }
+        // vmcnt counts in issue order: younger than this item's last DMA piece are the YOUNGER pieces of the P items behind it and the
+        // stores of the P iterations in between -- one discriminator store each, and the two stores of a band-pass batch in at
+        // least every second one (a batch closes every odd tile and every row's last).  Under-counting only waits longer.
+        if (steady) {
+            if (q < C::P) wait_vmcnt<C::YOUNGER>();
+            else wait_vmcnt<C::YOUNGER + C::P + 2 * (C::P / 2)>();
+        } else {
+            wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint8_t *bsrc = ring + slot * C::SLOT + lane_off;
+        i4 b[C::KSTEPS];
+#pragma unroll
+        for (int j = 0; j < C::KSTEPS; j++) b[j] = *reinterpret_cast<const i4 *>(bsrc + 64 * j);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        i4 acc[C::NDIG];
+#pragma unroll
+        for (int d = 0; d < C::NDIG; d++) acc[d] = (i4){0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < C::KSTEPS; j++) {
+            const i4 bs = b[j] ^ static_cast<int>(0x80808080u);
+#pragma unroll
+            for (int d = 0; d < C::NDIG; d++) acc[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[j][d], bs, acc[d], 0, 0, 0);
+        }
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int lo = acc[0][k];
+            if (C::NDIG >= 2) lo += acc[1][k] * 256;
+            const float flo = static_cast<float>(lo) * scale_lo;
+            v[k] = C::NDIG >= 3 ? __builtin_fmaf(static_cast<float>(acc[2][k]), scale_hi, flo) : flo;
+        }
+        const float pi = __shfl(v[2], src_lane, 64), pq = __shfl(v[3], src_lane, 64);
+        const float d0 = demod_fast(v[0], v[1], pi, pq), d1 = demod_fast(v[2], v[3], v[0], v[1]);
+        const int ot = C::COL_OUT * (col - 1) + 2 * g;             // this lane's first output inside the tile
+        const long ol = static_cast<long>(t) * C::TILE_OUT + ot;   // ... inside this launch's share of the row
+        if (col > 0) {
+            if (ol < bk.n_row) *reinterpret_cast<f2 *>(demod + c * bk.out_pitch + bk.out_off + ol) = (f2){d0, d1};
+            *reinterpret_cast<f2 *>(buf + HB + (t & 1) * C::TILE_OUT + ot) = (f2){d0, d1};
+        }
+        // ---- the band-pass pair over the batch that this tile completes (two tiles; the row's last tile alone if their number is odd) ----
+        if ((t & 1) || t == tpc - 1) {
+            const long o0 = static_cast<long>(t & ~1) * C::TILE_OUT;   // the batch's first output inside this launch's share of the row
+            f4 xs[AK / 4];
+#pragma unroll
+            for (int k = 0; k < AK / 4; k++) xs[k] = *reinterpret_cast<const f4 *>(buf + (HB - (TS - 1)) + 16 * col + 4 * g + 16 * k);
+            f4 ys = (f4){0.0f, 0.0f, 0.0f, 0.0f}, yc = ys;
+#pragma unroll
+            for (int j = 0; j < AK; j++) {
+                const float xv = xs[j / 4][j % 4];
+                ys = __builtin_amdgcn_mfma_f32_16x16x4f32(ast[j], xv, ys, 0, 0, 0);
+                yc = __builtin_amdgcn_mfma_f32_16x16x4f32(acar[j], xv, yc, 0, 0, 0);
+            }
+            const long ob = o0 + 16 * col + 4 * g;                 // this lane's 4 consecutive outputs
+            if (col < 15 && ob < bk.n_row) {                       // n_row is a multiple of 4 (host contract): whole groups
+                *reinterpret_cast<f4 *>(bpf + c * bpf_pitch + bpf_off + ob) = ys;
+                uint32_t code = 0;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float cv = yc[r];
+                    const bool ord = fabsf(cv) > 1e-20f && fabsf(cv) < 1e20f;
+                    code |= (ord ? (cv > 0.0f ? 0x01u : 0xffu) : 0u) << (8 * r);
+                }
+                *reinterpret_cast<uint32_t *>(car8 + c * car_pitch + car_off + ob) = code;
+            }
+            // the batch's last 128 samples become the history of the next one
+            const float k0 = buf[BATCH + lane], k1 = buf[BATCH + 64 + lane];
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+            buf[lane] = k0;
+            buf[64 + lane] = k1;
+        }
+        slot = slot + 1 == C::NSLOT ? 0 : slot + 1;
+        fill = fill + 1 == C::NSLOT ? 0 : fill + 1;
+        if (++t == tpc) {
+            t = 0;
+            c += n_waves;
+        }
+    }
+}
+
 // ============================================================================================
 // Fused mono chain: RF_FrontEnd + RF_MONO of modes 0/1 (src/project.cpp:82-128, 330-350;
 // src/threadMonoOnly.cpp:185-191) in ONE kernel: u8 I/Q in, float audio and/or s16 PCM out.  The
@@ -1110,6 +1284,61 @@ int fe_mfma_bank_launch(const FePlan &pl, const uint8_t *d_slots, long total_byt
     FMRX_FE_MFMA_CASES(X)
 #undef X
     return fail(FMRX_EINVAL, "fe_mfma_bank: no kernel for taps=%d decim=%d", pl.taps, pl.decim);
+}
+
+// front end + band-pass pair in one kernel (fe_bpf_bank_kernel): available for rf taps <= 101 and stereo taps <= 101 (register budget)
+bool fe_bpf_bank_available(const FePlan &pl, int stereo_taps)
+{
+    return pl.mfma && (pl.taps == 101 || pl.taps == 13) && (pl.decim == 10 || pl.decim == 5) && (stereo_taps == 101 || stereo_taps == 13);
+}
+
+int fe_bpf_tables_init(DevBuf<float> &st_img, DevBuf<float> &car_img, const float *h_st, const float *h_car, int taps)
+{
+    std::vector<float> tab;
+    audio_mfma_build_table(h_st, taps, 1, tab);
+    FMRX_TRY(st_img.alloc(tab.size()));
+    FMRX_HIP(hipMemcpy(st_img.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    audio_mfma_build_table(h_car, taps, 1, tab);
+    FMRX_TRY(car_img.alloc(tab.size()));
+    FMRX_HIP(hipMemcpy(car_img.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    return FMRX_OK;
+}
+
+int fe_bpf_bank_launch(const FePlan &pl, int stereo_taps, const float *d_st_img, const float *d_car_img, const uint8_t *d_slots,
+                       long total_bytes, long in_pitch, long block_off, int n_channels, long k_lo, long k_hi, float *d_demod,
+                       long out_pitch, long out_off, float *d_bpf, long bpf_pitch, int8_t *d_car8, long car_pitch, int wgs_per_cu_cap,
+                       hipStream_t stream)
+{
+    if (!fe_bpf_bank_available(pl, stereo_taps)) return fail(FMRX_EINVAL, "fe_bpf_bank: no fused kernel for these tap counts");
+    if ((k_hi - k_lo) % 4 || k_lo % 4 || (k_lo * pl.decim * 2) % 16 || in_pitch % 16 || block_off % 16 || out_pitch % 4 || (out_off + k_lo) % 4 ||
+        bpf_pitch % 4 || car_pitch % 4 || out_off < 128)
+        return fail(FMRX_EINVAL, "fe_bpf_bank: misaligned geometry");
+#define X(T_, D_, TS_)                                                                                                   \
+    if (pl.taps == T_ && pl.decim == D_ && stereo_taps == TS_) {                                                         \
+        using C = MfCfg<T_, D_>;                                                                                         \
+        FeBankGeom bk;                                                                                                   \
+        bk.in_pitch = in_pitch;                                                                                          \
+        bk.in_off = block_off + k_lo * D_ * 2;                                                                           \
+        bk.out_pitch = out_pitch;                                                                                        \
+        bk.out_off = out_off + k_lo;                                                                                     \
+        bk.n_row = k_hi - k_lo;                                                                                          \
+        bk.tiles_per_row = static_cast<int>((bk.n_row + C::TILE_OUT - 1) / C::TILE_OUT);                                  \
+        constexpr size_t lds_wave = C::RING + (128 + 2 * C::TILE_OUT + 32) * 4;                                          \
+        long wgs_per_cu = (160 * 1024) / (4L * lds_wave);                                                                \
+        if (wgs_per_cu > 2) wgs_per_cu = 2;                                                                              \
+        if (wgs_per_cu_cap >= 1 && wgs_per_cu_cap < wgs_per_cu) wgs_per_cu = wgs_per_cu_cap;                             \
+        const long want = (n_channels + 3) / 4;                                                                          \
+        const long grid = want < 256 * wgs_per_cu ? want : 256 * wgs_per_cu;                                             \
+        hipLaunchKernelGGL((fe_bpf_bank_kernel<T_, D_, TS_>), dim3(static_cast<unsigned>(grid)), dim3(256), 4 * lds_wave, stream,  \
+                           d_slots, total_bytes, reinterpret_cast<const i4 *>(pl.a_img.p), pl.scale_lo, d_st_img, d_car_img, d_demod, d_bpf,  \
+                           bpf_pitch, k_lo, d_car8, car_pitch, k_lo, bk, n_channels);                                    \
+        hipError_t e = hipGetLastError();                                                                                \
+        if (e != hipSuccess) return fail(FMRX_EHIP, "launch fe_bpf_bank_kernel<%d,%d,%d>: %s", T_, D_, TS_, hipGetErrorString(e)); \
+        return FMRX_OK;                                                                                                  \
+    }
+    X(101, 10, 101) X(101, 5, 101) X(13, 10, 13) X(13, 5, 13) X(101, 10, 13) X(101, 5, 13) X(13, 10, 101) X(13, 5, 101)
+#undef X
+    return fail(FMRX_EINVAL, "fe_bpf_bank: no kernel for taps=%d decim=%d stereo taps=%d", pl.taps, pl.decim, stereo_taps);
 }
 
 // Toeplitz image of the audio taps in A-operand order of v_mfma_f32_16x16x4_f32: [kstep][lane], lane

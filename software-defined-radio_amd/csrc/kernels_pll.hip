@@ -723,7 +723,10 @@ __global__ __launch_bounds__(64, 1) void pll_channels_kernel(const float *__rest
                                                            float *__restrict__ nco0, PllCoef c)
 {
     typedef float f4 __attribute__((ext_vector_type(4)));
-    constexpr int kBatch = 32;                                 // samples per lane and batch = one 128-byte line of its row
+    // samples per lane and batch.  Exact: 32 (one 128-byte line of a float row; 14 us of chain).  Fast: 64 -- a batch must outlast the
+    // memory latency UNDER LOAD (the lanes run next to kernels that saturate HBM: a request then takes ~5 us, and 32 fast steps are
+    // 2.7 us: the recurrence ran 2.7 x slower next to the bank's other kernels than alone)
+    constexpr int kBatch = MATH == kFast ? 64 : 32;
     __shared__ uint32_t w24[24];
     __shared__ float lin[kBatch * 64], lout[kBatch * 64];      // [sample][lane]: every lane reads and writes its own column
     if (threadIdx.x < 24) w24[threadIdx.x] = glibc235::inv_pio4(threadIdx.x);
@@ -778,11 +781,11 @@ __global__ __launch_bounds__(64, 1) void pll_channels_kernel(const float *__rest
     // with loads and stores inside the loop of steps every group of four steps paid a memory round trip.)
     const long nb = n / kBatch;
     f4 pre[IN8 ? 1 : kBatch / 4];
-    i4v pre8[2];                                               // IN8: 32 signed bytes
+    i4v pre8[kBatch / 16];                                     // IN8: kBatch signed bytes
     if (nb > 0) {
         if (IN8) {
-            pre8[0] = reinterpret_cast<const i4v *>(in8)[0];
-            pre8[1] = reinterpret_cast<const i4v *>(in8)[1];
+#pragma unroll
+            for (int g = 0; g < kBatch / 16; g++) pre8[g] = reinterpret_cast<const i4v *>(in8)[g];
         } else {
 #pragma unroll
             for (int g = 0; g < kBatch / 4; g++) pre[g] = in4[g];
@@ -795,8 +798,8 @@ __global__ __launch_bounds__(64, 1) void pll_channels_kernel(const float *__rest
             for (int j = 0; j < kBatch; j++)
                 lin[j * 64 + lane] = static_cast<float>(static_cast<int8_t>((pre8[j / 16][(j / 4) % 4] >> (8 * (j % 4))) & 0xff));
             if (b + 1 < nb) {
-                pre8[0] = reinterpret_cast<const i4v *>(in8 + (b + 1) * kBatch)[0];
-                pre8[1] = reinterpret_cast<const i4v *>(in8 + (b + 1) * kBatch)[1];
+#pragma unroll
+                for (int g = 0; g < kBatch / 16; g++) pre8[g] = reinterpret_cast<const i4v *>(in8 + (b + 1) * kBatch)[g];
             }
         } else {
 #pragma unroll

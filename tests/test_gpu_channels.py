@@ -107,7 +107,8 @@ def test_bank_other_block_sizes(fmrx, oracle):
         fmrx.Channels(2, 4, audio_channels=2, exact=True, block_bytes=16160)     # 808 IF samples: a block must end on an output boundary (n_if * U % D == 0)
 
 
-def test_stereo_bank_fast_error_envelope(fmrx, oracle):
+@pytest.mark.parametrize("fused", [0, 1], ids=["two kernels", "front end + band-pass pair in one kernel"])
+def test_stereo_bank_fast_error_envelope(fmrx, oracle, fused):
     """The FAST stereo bank (exact = 0: matrix-core front end, one fma per tap in the band-pass pair and the audio FIRs, the
     PLL's fast recurrence walked by one lane per channel) promises what the default single-stream path promises
     (tests/test_gpu_parity.py: ENVELOPE_FACTOR): per channel and 0.1 s window, audio RMS error <= max(1e-4, 0.06
@@ -118,7 +119,11 @@ def test_stereo_bank_fast_error_envelope(fmrx, oracle):
     N, nblk, bb = 24, 100, p.block_bytes
     with ProcessPoolExecutor(max_workers=min(12, os.cpu_count() or 1)) as ex:
         res = sorted(ex.map(_oracle_channel, [(c, nblk, bb, float(p.rf_Fs)) for c in range(N)], chunksize=2), key=lambda r: r[0])
-    ch = fmrx.Channels(0, N, audio_channels=2, exact=False)
+    fmrx.set_option("bank_fused", fused)                    # a bank copies the process-wide options when it is created
+    try:
+        ch = fmrx.Channels(0, N, audio_channels=2, exact=False)
+    finally:
+        fmrx.set_option("bank_fused", 0)
     L = np.zeros((N, nblk * 1024), np.float32)
     R = np.zeros((N, nblk * 1024), np.float32)
     for b in range(nblk):
