@@ -382,11 +382,14 @@ __global__ __launch_bounds__(256) void chs_nco_kernel(float *__restrict__ trig, 
 // one-read-per-tap form is bound by LDS bandwidth at twice the time), the taps of two steps are one scalar load.
 // Neighbouring lanes' windows start R*D pairs apart; the LDS index j + j / (R*D) makes that an odd number of
 // pairs (41 / 49): conflict-free ds_read_b64.  Mono banks (STEREO = false) run the same kernel on the mono half alone.
+constexpr int kRO = 4;   // adjacent audio outputs per thread of the output stage (8: 512 outputs and 22 KB of LDS per workgroup -- 7 single-wave
+                         // workgroups per CU, whose staging latency then sets the kernel's time; 4: 256 outputs, 11 KB, 14 per CU)
 template <int T, int D>
 struct OutX {
-    static constexpr int R = kR;
+    static constexpr int R = kRO;
+    static constexpr int SPL = 16 / R;                          // steps per scalar load of 16 taps
     static constexpr int W = D * (R - 1) + T;                   // window samples (= steps) per thread
-    static constexpr int NG = (W + 1) / 2;                      // scalar-load groups: two steps each
+    static constexpr int NG = (W + SPL - 1) / SPL;              // scalar-load groups
     static constexpr int NOUT = 64 * R;                         // audio outputs per workgroup
     static constexpr int WL = D * (NOUT - 1) + T;               // window samples per workgroup
     static constexpr int SEG = R * D;                           // window samples between neighbouring lanes
@@ -395,7 +398,7 @@ struct OutX {
 };
 
 template <int T, int D, bool STEREO, bool EXACT, int G>
-__device__ __forceinline__ void outx_step(const f2 *__restrict__ wl, const float *__restrict__ table, f2 (&acc)[kR], f16v &hA, f16v &hB)
+__device__ __forceinline__ void outx_step(const f2 *__restrict__ wl, const float *__restrict__ table, f2 (&acc)[kRO], f16v &hA, f16v &hB)
 {
     using C = OutX<T, D>;
     if constexpr (G < C::NG) {
@@ -412,16 +415,16 @@ __device__ __forceinline__ void outx_step(const f2 *__restrict__ wl, const float
             for (int k = 0; k < 16; k++) hq[k] = hB[k];
         }
 #pragma unroll
-        for (int e = 0; e < 2; e++) {
-            const int u = 2 * G + e;
+        for (int e = 0; e < C::SPL; e++) {
+            const int u = C::SPL * G + e;
             if (u < C::W) {
                 const int jj = C::W - 1 - u;                    // window sample of this thread, newest first
                 const f2 w = wl[C::idx(jj)];                    // lane base + compile-time offset
 #pragma unroll
-                for (int r = 0; r < kR; r++) {
+                for (int r = 0; r < kRO; r++) {
                     const int n = r * D + (T - 1) - jj;
                     if (n >= 0 && n < T) {
-                        const float h = hq[8 * e + r];
+                        const float h = hq[kRO * e + r];
                         if constexpr (!EXACT) {
                             acc[r] = __builtin_elementwise_fma(w, (f2){h, h}, acc[r]);
                         } else if constexpr (STEREO) {
@@ -436,7 +439,7 @@ __device__ __forceinline__ void outx_step(const f2 *__restrict__ wl, const float
             }
         }
 #pragma unroll
-        for (int r = 0; r < kR; r++) asm volatile("" : "+v"(acc[r]));
+        for (int r = 0; r < kRO; r++) asm volatile("" : "+v"(acc[r]));
         outx_step<T, D, STEREO, EXACT, G + 1>(wl, table, acc, hA, hB);
     }
 }
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(64) void chs_out_kernel(const float *__restrict__ d
                                                             int16_t *__restrict__ pcm, int wrap, long a_lo, long a_hi, long n_out)
 {
     using C = OutX<T, D>;
-    constexpr int R = kR;
+    constexpr int R = kRO;
     __shared__ f2 win[C::LDSN];
     const int t = threadIdx.x;
     const long c = blockIdx.x / wgs_per_channel;
@@ -468,7 +471,7 @@ __global__ __launch_bounds__(64) void chs_out_kernel(const float *__restrict__ d
     // Staging in batches of B samples per lane, the next batch's three loads per sample in flight while this one is turned into
     // LDS pairs.  EXACT: `nco` holds finished NCO values (chs_nco_kernel); fast bank: the raw trigArg of the PLL's steps, and the
     // cosine is taken here (one argument reduction in double + the hardware cosine, kernels_pll.hip: nco_out<kFast>).
-    constexpr int NJ = (C::WL + D - 1 + 63) / 64, B = 11, NBATCH = (NJ + B - 1) / B;
+    constexpr int NJ = (C::WL + D - 1 + 63) / 64, B = kRO == 4 ? 11 : 11, NBATCH = (NJ + B - 1) / B;
     float vm[2][B], va[2][B], vb[2][B];
     auto fetch = [&](int q0, float (&m)[B], float (&a)[B], float (&b)[B]) __attribute__((always_inline)) {
 #pragma unroll
@@ -536,18 +539,20 @@ __global__ __launch_bounds__(64) void chs_out_kernel(const float *__restrict__ d
         if (k0 + R <= a_hi) {
             if (audio) {
                 f4 *pl = reinterpret_cast<f4 *>(audio + c * 2 * n_out + k0), *pr = reinterpret_cast<f4 *>(audio + c * 2 * n_out + n_out + k0);
-                pl[0] = (f4){l[0], l[1], l[2], l[3]};
-                pl[1] = (f4){l[4], l[5], l[6], l[7]};
-                pr[0] = (f4){rr[0], rr[1], rr[2], rr[3]};
-                pr[1] = (f4){rr[4], rr[5], rr[6], rr[7]};
+#pragma unroll
+                for (int q = 0; q < R / 4; q++) {
+                    pl[q] = (f4){l[4 * q], l[4 * q + 1], l[4 * q + 2], l[4 * q + 3]};
+                    pr[q] = (f4){rr[4 * q], rr[4 * q + 1], rr[4 * q + 2], rr[4 * q + 3]};
+                }
             }
             if (pcm) {
                 using s8v = short __attribute__((ext_vector_type(8)));
                 s8v *pp = reinterpret_cast<s8v *>(pcm + 2 * (c * n_out + k0));
-                pp[0] = (s8v){pcm_pack_flat(l[0], wrap), pcm_pack_flat(rr[0], wrap), pcm_pack_flat(l[1], wrap), pcm_pack_flat(rr[1], wrap),
-                              pcm_pack_flat(l[2], wrap), pcm_pack_flat(rr[2], wrap), pcm_pack_flat(l[3], wrap), pcm_pack_flat(rr[3], wrap)};
-                pp[1] = (s8v){pcm_pack_flat(l[4], wrap), pcm_pack_flat(rr[4], wrap), pcm_pack_flat(l[5], wrap), pcm_pack_flat(rr[5], wrap),
-                              pcm_pack_flat(l[6], wrap), pcm_pack_flat(rr[6], wrap), pcm_pack_flat(l[7], wrap), pcm_pack_flat(rr[7], wrap)};
+#pragma unroll
+                for (int q = 0; q < R / 4; q++)
+                    pp[q] = (s8v){pcm_pack_flat(l[4 * q], wrap), pcm_pack_flat(rr[4 * q], wrap), pcm_pack_flat(l[4 * q + 1], wrap),
+                                  pcm_pack_flat(rr[4 * q + 1], wrap), pcm_pack_flat(l[4 * q + 2], wrap), pcm_pack_flat(rr[4 * q + 2], wrap),
+                                  pcm_pack_flat(l[4 * q + 3], wrap), pcm_pack_flat(rr[4 * q + 3], wrap)};
             }
         } else {
 #pragma unroll
@@ -827,9 +832,9 @@ int out_table_init(StereoBank &b, const float *h)
     using C = OutX<T, D>;
     std::vector<float> tab(static_cast<size_t>(C::NG) * 16, 0.0f);
     for (int u = 0; u < C::W; u++)
-        for (int r = 0; r < kR; r++) {
+        for (int r = 0; r < kRO; r++) {
             const int n = r * D + (T - 1) - (C::W - 1 - u);
-            if (n >= 0 && n < T) tab[static_cast<size_t>(u) * 8 + r] = h[n];
+            if (n >= 0 && n < T) tab[static_cast<size_t>(u) * kRO + r] = h[n];
         }
     FMRX_TRY(b.out_table.alloc(tab.size()));
     FMRX_HIP(hipMemcpy(b.out_table.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
