@@ -970,8 +970,8 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
         pq = lane == 0 ? cq : pq;
         ci = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[2]), 63));
         cq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[3]), 63));
-        const float d0 = demod_fast(v[0], v[1], pi, pq);
-        const float d1 = demod_fast(v[2], v[3], v[0], v[1]);
+        const float d0 = (DBG & 1048576) ? v[0] * pq - v[1] * pi : demod_fast(v[0], v[1], pi, pq);   // 1048576: no division (timing only)
+        const float d1 = (DBG & 1048576) ? v[2] * v[1] - v[3] * v[0] : demod_fast(v[2], v[3], v[0], v[1]);
         const int ol = F::COL_OUT * col + 2 * g;
         *reinterpret_cast<f2 *>(dring + dpos + ol) = (f2){d0, d1};
         if (dpos == 0 && ol < C::MIRROR) *reinterpret_cast<f2 *>(dring + C::DR + ol) = (f2){d0, d1};
@@ -1245,6 +1245,13 @@ int fe_mfma_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, cons
         return launch_mfma<101, 10, 2, 3, G_>(pl, d_iq, n_samples, d_hist, d_prev, d_demod, d_if, d_prev_out, d_hist_next, o, stream);
         Y(1) Y(2) Y(3) Y(8)
 #undef Y
+        // D = 3 / 5 with more workgroups per CU: 30000 + D*1000 + MINB*100 + P
+#define Y(D_, B_, P_) \
+    if (pl.taps == 101 && pl.decim == D_ && v == 30000 + D_ * 1000 + B_ * 100 + P_) \
+        return launch_mfma<101, D_, B_, P_>(pl, d_iq, n_samples, d_hist, d_prev, d_demod, d_if, d_prev_out, d_hist_next, o, stream, \
+                                            d_dhist_src, d_dhist_dst, dhist_n);
+        Y(3, 2, 8) Y(3, 3, 8) Y(3, 4, 8) Y(3, 4, 4) Y(3, 3, 4) Y(3, 4, 6) Y(5, 2, 5) Y(5, 3, 5) Y(5, 3, 3) Y(5, 4, 3) Y(5, 4, 2)
+#undef Y
         if (pl.taps == 101 && v == 1600) {   // general loop only (A/B of the straight-line interior loop), any decimation
 #define Y(D_) \
     if (pl.decim == D_) return launch_mfma<101, D_, 2, 0, 16>(pl, d_iq, n_samples, d_hist, d_prev, d_demod, d_if, d_prev_out, d_hist_next, o, stream, \
@@ -1254,10 +1261,14 @@ int fe_mfma_launch(const FePlan &pl, const uint8_t *d_iq, size_t n_samples, cons
         }
     }
 #endif
+    // workgroups per CU / tiles in flight: the D = 3 / 5 kernels move few bytes per tile and gain from more waves per SIMD with a
+    // shallower ring (tools/fe_mfma_tune_modes.py, whole steps: mode 3 0.0754 -> 0.0705 ms with <3, 4>, the decimate-by-5 step
+    // 0.0382 -> 0.0356 ms with <4, 2>); longer filters keep two (their tap image alone is > 64 registers)
 #define X(T_, D_) \
     if (pl.taps == T_ && pl.decim == D_) \
-        return launch_mfma<T_, D_>(pl, d_iq, n_samples, d_hist, d_prev, d_demod, d_if, d_prev_out, d_hist_next, o, stream, \
-                                   d_dhist_src, d_dhist_dst, dhist_n);
+        return launch_mfma<T_, D_, (T_ <= 101 && D_ == 3) ? 3 : (T_ <= 101 && D_ == 5) ? 4 : 2, \
+                           (T_ <= 101 && D_ == 3) ? 4 : (T_ <= 101 && D_ == 5) ? 2 : 0>( \
+            pl, d_iq, n_samples, d_hist, d_prev, d_demod, d_if, d_prev_out, d_hist_next, o, stream, d_dhist_src, d_dhist_dst, dhist_n);
     FMRX_FE_MFMA_CASES(X)
 #undef X
     return fail(FMRX_EINVAL, "fe_mfma_launch: no kernel for taps=%d decim=%d", pl.taps, pl.decim);
@@ -1379,6 +1390,14 @@ int mono_fused_launch(const FePlan &fe, const AudioPlan &au, const uint8_t *d_iq
                                                                   d_demod_tail, tail_keep, d_prev_out, d_audio, d_pcm, wrap, \
                                                                   d_hist_next, o, stream);
         Y(2, 2, 0, 0, 0) Y(12, 2, 0, 1, 0) Y(1, 1, 0, 0, 0) Y(82, 2, 0, 8, 0) Y(102, 2, 0, 10, 0) Y(162, 2, 0, 16, 0) Y(224, 2, 0, 0, 24) Y(324, 3, 0, 0, 24) Y(216, 2, 0, 0, 16) Y(212, 2, 0, 0, 12) Y(20482, 2, 0, 2048, 0) Y(262, 2, 0, 26, 0) Y(172, 2, 0, 17, 0) Y(10252, 2, 0, 1025, 0) Y(5222, 2, 0, 522, 0) Y(5122, 2, 0, 512, 0) Y(22, 2, 0, 2, 0) Y(42, 2, 0, 4, 0) Y(1282, 2, 0, 128, 0) Y(2562, 2, 0, 256, 0) Y(3842, 2, 0, 384, 0) Y(3852, 2, 0, 385, 0) Y(40962, 2, 0, 4096, 0) Y(2621442, 2, 0, 262144, 0) Y(5242882, 2, 0, 524288, 0) Y(1310722, 2, 0, 131072, 0) Y(655362, 2, 0, 65536, 0) Y(655372, 2, 0, 65537, 0) Y(327682, 2, 0, 32768, 0) Y(81922, 2, 0, 8192, 0) Y(245762, 2, 0, 24576, 0)
+#undef Y
+        // mode 1's shape (101,5,101,6): 5000 + DBG
+#define Y(G_)                                                                                                              \
+    if (fe.taps == 101 && fe.decim == 5 && au.taps == 101 && au.decim == 6 && v == 5000 + G_)                                \
+        return launch_fused_mono<101, 5, 101, 6, 0, 0, G_, 0>(fe, au, d_iq, n_samples, d_hist, d_prev, d_dhist_end,         \
+                                                              d_demod_tail, tail_keep, d_prev_out, d_audio, d_pcm, wrap,   \
+                                                              d_hist_next, o, stream);
+        Y(0) Y(1) Y(2) Y(4) Y(8) Y(16) Y(128) Y(256) Y(384) Y(388) Y(389) Y(400) Y(512) Y(514) Y(4096) Y(65536) Y(1048576) Y(1048960) Y(1049474)
 #undef Y
     }
 #endif
