@@ -377,11 +377,11 @@ __global__ __launch_bounds__(256) void chs_nco_kernel(float *__restrict__ trig, 
 // and the interleaved PCM writer (:292-302), in the reference's evaluation order.  A single-wave workgroup stages the
 // window of its 64*R audio outputs as (mono, mixer) pairs in LDS -- the mixer products are formed while staging and never
 // go to HBM; the two FIRs share the taps, so they ride in the two halves of the packed instructions.  The FIR is the
-// front end's scheme once more: a thread owns R = 8 ADJACENT outputs and visits its window newest sample first, one
-// ds_read_b64 per sample feeds every output the sample belongs to (136 LDS reads per 808 tap-output pairs: the
+// front end's scheme once more: a thread owns R = kRO ADJACENT outputs and visits its window newest sample first, one
+// ds_read_b64 per sample feeds every output the sample belongs to (R = 4: 116 LDS reads per 404 tap-output pairs; the
 // one-read-per-tap form is bound by LDS bandwidth at twice the time), the taps of two steps are one scalar load.
 // Neighbouring lanes' windows start R*D pairs apart; the LDS index j + j / (R*D) makes that an odd number of
-// pairs (41 / 49): conflict-free ds_read_b64.  Mono banks (STEREO = false) run the same kernel on the mono half alone.
+// pairs (R = 4: 21 / 25): conflict-free ds_read_b64.  Mono banks (STEREO = false) run the same kernel on the mono half alone.
 constexpr int kRO = 4;   // adjacent audio outputs per thread of the output stage (8: 512 outputs and 22 KB of LDS per workgroup -- 7 single-wave
                          // workgroups per CU, whose staging latency then sets the kernel's time; 4: 256 outputs, 11 KB, 14 per CU)
 template <int T, int D>

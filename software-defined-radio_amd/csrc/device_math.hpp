@@ -46,6 +46,18 @@ __device__ __forceinline__ float demod_fast(float i, float q, float pi, float pq
     return den == 0.0f ? 0.0f : quot;                                // select, not a branch: every lane runs both anyway
 }
 
+// The same for operands known to be 0 or of ordinary size (the matrix-core kernels' straight-line tiles: an IF sample is an
+// integer times the plan's scale 2^-(s+7), and those tiles run only when that scale is >= 2^-50): no denominator is tiny, so
+// the 2^64 scaling of demod_fast (a compare, a select and two multiplies per output) selects 1 every time and is left out.
+// Bit-identical to demod_fast on those operands.
+__device__ __forceinline__ float demod_fast_bounded(float i, float q, float pi, float pq)
+{
+    const float den = i * i + q * q;
+    const float num = i * (q - pq) - q * (i - pi);
+    const float quot = num * __builtin_amdgcn_rcpf(den);
+    return den == 0.0f ? 0.0f : quot;
+}
+
 // PCM pack of src/threadMonoOnly.cpp:185-191: NaN -> 0 else (short)(a*16384).
 // wrap: what the compiled reference does out of range (cvttss2si, low 16 bits).
 __device__ __forceinline__ int16_t pcm_pack(float a, int wrap)

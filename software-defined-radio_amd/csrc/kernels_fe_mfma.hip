@@ -240,8 +240,8 @@ __global__ __launch_bounds__(256, MINB) void fe_mfma_kernel(
         float d0 = 0.0f, d1 = 0.0f;
         if constexpr ((MODE & 1) != 0) {
             const float pi = __shfl(v[2], src_lane, 64), pq = __shfl(v[3], src_lane, 64);
-            d0 = demod_fast(v[0], v[1], pi, pq);
-            d1 = demod_fast(v[2], v[3], v[0], v[1]);
+            d0 = demod_fast_bounded(v[0], v[1], pi, pq);
+            d1 = demod_fast_bounded(v[2], v[3], v[0], v[1]);
         }
         if (col > 0) {
             if constexpr ((MODE & 1) != 0) *reinterpret_cast<f2 *>(demod + o) = (f2){d0, d1};
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256, MINB) void fe_mfma_kernel(
     long it_end = 0;
     // measured (tools/fe_mfma_tune_modes.py, whole step): D = 3 0.096 -> 0.084 ms, D = 5 0.041 -> 0.038 ms; D = 10 sits at the
     // streaming rate of the LDS-DMA ring either way (0.0396 vs 0.0408 ms): general loop there
-    if (!(DBG & 16) && D < 10) {
+    if (!(DBG & 16) && D < 10 && scale_lo >= 8.8817842e-16f) {    // 2^-50: demod_fast_bounded's precondition
         const long nt = n_tiles, ts = tstep;
         // (a) tile + P*tstep exists and its window is read whole from the block; (b) the tile's outputs and the pair behind exist
         const long last_dma = (n_bytes - C::NP * 1024L + C::LEAD) / C::STRIDE_BYTES;   // last tile whose window fits
@@ -888,7 +888,7 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
     //      scalar branches per tile.  Tiles [tb, t_fast0) and [t_fast1, t1) stay with the general loop. --------------
     int t_fast1 = 0;                                               // first tile that is not in a straight-line steady batch
     bool fast_last = false;                                        // the run's last batch [t1 - TB, t1) runs straight-line too
-    if (!(DBG & 4096)) {
+    if (!(DBG & 4096) && scale_lo >= 8.8817842e-16f) {             // 2^-50: demod_fast_bounded's precondition
         // tile t may issue the DMA of tile t + P + 1 without looking if that tile is read whole from the block ...
         const long in_x = (n_bytes - C::NP * 1024L + F::FRONT) / C::TILE_BYTES;              // last such tile
         const long no_tail = (n_out - tail_keep) / C::TILE_OUT - 1;                          // ... (t+1)*128 <= n_out - tail_keep
@@ -970,8 +970,9 @@ __global__ __launch_bounds__(256, 2) void mono_fused_kernel(
         pq = lane == 0 ? cq : pq;
         ci = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[2]), 63));
         cq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[3]), 63));
-        const float d0 = (DBG & 1048576) ? v[0] * pq - v[1] * pi : demod_fast(v[0], v[1], pi, pq);   // 1048576: no division (timing only)
-        const float d1 = (DBG & 1048576) ? v[2] * v[1] - v[3] * v[0] : demod_fast(v[2], v[3], v[0], v[1]);
+        // 1048576: no division (timing only); 2097152: the general form with its tiny-denominator scaling (A/B)
+        const float d0 = (DBG & 1048576) ? v[0] * pq - v[1] * pi : (DBG & 2097152) ? demod_fast(v[0], v[1], pi, pq) : demod_fast_bounded(v[0], v[1], pi, pq);
+        const float d1 = (DBG & 1048576) ? v[2] * v[1] - v[3] * v[0] : (DBG & 2097152) ? demod_fast(v[2], v[3], v[0], v[1]) : demod_fast_bounded(v[2], v[3], v[0], v[1]);
         const int ol = F::COL_OUT * col + 2 * g;
         *reinterpret_cast<f2 *>(dring + dpos + ol) = (f2){d0, d1};
         if (dpos == 0 && ol < C::MIRROR) *reinterpret_cast<f2 *>(dring + C::DR + ol) = (f2){d0, d1};
@@ -1389,7 +1390,7 @@ int mono_fused_launch(const FePlan &fe, const AudioPlan &au, const uint8_t *d_iq
         return launch_fused_mono<101, 10, 101, 5, P_, DR_, G_, K_>(fe, au, d_iq, n_samples, d_hist, d_prev, d_dhist_end,    \
                                                                   d_demod_tail, tail_keep, d_prev_out, d_audio, d_pcm, wrap, \
                                                                   d_hist_next, o, stream);
-        Y(2, 2, 0, 0, 0) Y(12, 2, 0, 1, 0) Y(1, 1, 0, 0, 0) Y(82, 2, 0, 8, 0) Y(102, 2, 0, 10, 0) Y(162, 2, 0, 16, 0) Y(224, 2, 0, 0, 24) Y(324, 3, 0, 0, 24) Y(216, 2, 0, 0, 16) Y(212, 2, 0, 0, 12) Y(20482, 2, 0, 2048, 0) Y(262, 2, 0, 26, 0) Y(172, 2, 0, 17, 0) Y(10252, 2, 0, 1025, 0) Y(5222, 2, 0, 522, 0) Y(5122, 2, 0, 512, 0) Y(22, 2, 0, 2, 0) Y(42, 2, 0, 4, 0) Y(1282, 2, 0, 128, 0) Y(2562, 2, 0, 256, 0) Y(3842, 2, 0, 384, 0) Y(3852, 2, 0, 385, 0) Y(40962, 2, 0, 4096, 0) Y(2621442, 2, 0, 262144, 0) Y(5242882, 2, 0, 524288, 0) Y(1310722, 2, 0, 131072, 0) Y(655362, 2, 0, 65536, 0) Y(655372, 2, 0, 65537, 0) Y(327682, 2, 0, 32768, 0) Y(81922, 2, 0, 8192, 0) Y(245762, 2, 0, 24576, 0)
+        Y(2, 2, 0, 0, 0) Y(12, 2, 0, 1, 0) Y(1, 1, 0, 0, 0) Y(82, 2, 0, 8, 0) Y(102, 2, 0, 10, 0) Y(162, 2, 0, 16, 0) Y(224, 2, 0, 0, 24) Y(324, 3, 0, 0, 24) Y(216, 2, 0, 0, 16) Y(212, 2, 0, 0, 12) Y(20482, 2, 0, 2048, 0) Y(262, 2, 0, 26, 0) Y(172, 2, 0, 17, 0) Y(10252, 2, 0, 1025, 0) Y(5222, 2, 0, 522, 0) Y(5122, 2, 0, 512, 0) Y(22, 2, 0, 2, 0) Y(42, 2, 0, 4, 0) Y(1282, 2, 0, 128, 0) Y(2562, 2, 0, 256, 0) Y(3842, 2, 0, 384, 0) Y(3852, 2, 0, 385, 0) Y(40962, 2, 0, 4096, 0) Y(2621442, 2, 0, 262144, 0) Y(5242882, 2, 0, 524288, 0) Y(1310722, 2, 0, 131072, 0) Y(655362, 2, 0, 65536, 0) Y(655372, 2, 0, 65537, 0) Y(327682, 2, 0, 32768, 0) Y(81922, 2, 0, 8192, 0) Y(245762, 2, 0, 24576, 0) Y(3, 0, 0, 2097152, 0) Y(4, 0, 0, 0, 0)
 #undef Y
         // mode 1's shape (101,5,101,6): 5000 + DBG
 #define Y(G_)                                                                                                              \
@@ -1397,7 +1398,7 @@ int mono_fused_launch(const FePlan &fe, const AudioPlan &au, const uint8_t *d_iq
         return launch_fused_mono<101, 5, 101, 6, 0, 0, G_, 0>(fe, au, d_iq, n_samples, d_hist, d_prev, d_dhist_end,         \
                                                               d_demod_tail, tail_keep, d_prev_out, d_audio, d_pcm, wrap,   \
                                                               d_hist_next, o, stream);
-        Y(0) Y(1) Y(2) Y(4) Y(8) Y(16) Y(128) Y(256) Y(384) Y(388) Y(389) Y(400) Y(512) Y(514) Y(4096) Y(65536) Y(1048576) Y(1048960) Y(1049474)
+        Y(0) Y(2097152) Y(1) Y(2) Y(4) Y(8) Y(16) Y(128) Y(256) Y(384) Y(388) Y(389) Y(400) Y(512) Y(514) Y(4096) Y(65536) Y(1048576) Y(1048960) Y(1049474)
 #undef Y
     }
 #endif
