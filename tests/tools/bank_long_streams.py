@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Receiver banks over LONG streams against the oracle (checker script: it imports the oracle, so it lives under tests/).
-  python3 tests/tools/bank_long_streams.py [seconds] [channels]
+  python3 tests/tools/bank_long_streams.py [seconds] [channels] [mode]
 exact bank: left / right bit-identical over the whole stream (reported: first differing sample, if any);
-fast bank:  RMS error per 1 s window in units of ulp(trigArg(t)) (the envelope of DESIGN.md section 2: bound 0.06)."""
+fast bank (modes 0/1):  RMS error per 1 s window in units of ulp(trigArg(t)) (the envelope of DESIGN.md section 2: bound 0.06)."""
 import importlib, os, sys, time
 from concurrent.futures import ProcessPoolExecutor
 import numpy as np
@@ -13,10 +13,10 @@ for p in (ROOT, os.path.dirname(HERE)):
 from _oracle import Oracle
 
 def work(args):
-    c, nblk, bb = args
+    c, nblk, bb, mode, fs = args
     o = Oracle()
-    iq = o.synth_fm_u8(bb // 2 * nblk, seed=0x3D74 + c, start=7919 * c)
-    pl = o.pipeline(0, 2)
+    iq = o.synth_fm_u8(bb // 2 * nblk, fs, seed=0x3D74 + c, start=7919 * c)
+    pl = o.pipeline(mode, 2)
     L, R = [], []
     for b in range(nblk):
         out = pl.process(iq[b * bb:(b + 1) * bb])
@@ -30,19 +30,22 @@ def ulp_trig(t, if_Fs=240e3, freq=19e3):
 if __name__ == "__main__":
     secs = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
     N = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    mode = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     fmrx = importlib.import_module("software-defined-radio_amd")
-    bb = 102400
-    nblk = int(secs * 2.4e6 / 51200)
+    mp = fmrx.modeParams(mode)
+    bb, fs = int(mp.block_bytes), float(mp.rf_Fs)
+    nblk = int(secs * fs / (bb // 2))
     t0 = time.time()
     with ProcessPoolExecutor(max_workers=min(N, 12)) as ex:
-        res = sorted(ex.map(work, [(c, nblk, bb) for c in range(N)]), key=lambda r: r[0])
-    print(f"# {N} receivers x {nblk} reference blocks = {nblk * 51200 / 2.4e6:.1f} s of mode-0 stereo each; oracle done in {time.time() - t0:.0f} s", flush=True)
-    for exact in (True, False):
-        ch = fmrx.Channels(0, N, audio_channels=2, exact=exact)
-        L = np.zeros((N, nblk * 1024), np.float32); R = np.zeros_like(L)
+        res = sorted(ex.map(work, [(c, nblk, bb, mode, fs) for c in range(N)]), key=lambda r: r[0])
+    na = len(res[0][2]) // nblk                                # audio samples per reference block
+    print(f"# {N} receivers x {nblk} reference blocks = {nblk * (bb // 2) / fs:.1f} s of mode-{mode} stereo each; oracle done in {time.time() - t0:.0f} s", flush=True)
+    for exact in ((True, False) if mode < 2 else (True,)):
+        ch = fmrx.Channels(mode, N, audio_channels=2, exact=exact)
+        L = np.zeros((N, nblk * na), np.float32); R = np.zeros_like(L)
         for b in range(nblk):
             out = ch.process(np.stack([r[1][b * bb:(b + 1) * bb] for r in res]), want_pcm=False)
-            L[:, b * 1024:(b + 1) * 1024] = out["audio_l"]; R[:, b * 1024:(b + 1) * 1024] = out["audio_r"]
+            L[:, b * na:(b + 1) * na] = out["audio_l"]; R[:, b * na:(b + 1) * na] = out["audio_r"]
         if exact:
             for c in range(N):
                 dl = np.flatnonzero(L[c].view(np.uint32) != res[c][2].view(np.uint32))
@@ -50,15 +53,16 @@ if __name__ == "__main__":
                 print(f"exact bank, receiver {c}: {L.shape[1]} audio samples per side; differing bit patterns: left {len(dl)}, right {len(dr)}"
                       + (f" (first at {dl[0] if len(dl) else dr[0]})" if len(dl) + len(dr) else ""))
         else:
-            win = 48000
+            win = int(round(na * fs / (bb // 2)))               # one second of audio
             nw = L.shape[1] // win
             t_end = np.arange(1, nw + 1, dtype=np.float64)
+            if_fs = fs / float(mp.rf_decim)
             worst = np.zeros(nw)
             for c in range(N):
                 for got, want in ((L[c], res[c][2]), (R[c], res[c][3])):
                     d = (got[:nw * win].astype(np.float64) - want[:nw * win]).reshape(nw, win)
-                    worst = np.maximum(worst, np.sqrt((d * d).mean(axis=1)) / ulp_trig(t_end))
+                    worst = np.maximum(worst, np.sqrt((d * d).mean(axis=1)) / ulp_trig(t_end, if_fs))
             print("fast bank: worst RMS error over the receivers, per 1 s window, in ulp(trigArg(t)) (bound 0.06):")
             print("  " + " ".join(f"{w:.3f}" for w in worst))
-            print(f"  max {worst.max():.3f}; absolute RMS error in the last window {worst[-1] * ulp_trig(t_end[-1]):.2e}")
+            print(f"  max {worst.max():.3f}; absolute RMS error in the last window {worst[-1] * ulp_trig(t_end[-1], if_fs):.2e}")
         ch.close()
