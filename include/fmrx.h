@@ -337,14 +337,15 @@ FMRX_API int fmrx_channels_create(fmrx_channels **out, const fmrx_params *p, int
  *                   to run stereo within the 1e-4 bound at speed: the recurrence cannot be cut in time without leaving
  *                   the reference's trajectory, but receivers are independent (one STATES set
  *                   each, src/project.cpp:455-468).
- *                   0 = the specialised kernels: mono, fmrx_channels_create's bank; stereo, the matrix-core front end, one fused
+ *                   0 = the specialised kernels: mono, fmrx_channels_create's bank (modes 0, 1: one fused kernel); stereo, the matrix-core front end, one fused
  *                   multiply-add per tap in the band-pass pair and the audio FIRs, and the PLL's fast recurrence (closed-form phase
  *                   detector, hardware sine / cosine) walked by one lane per channel -- the error bound of the default
  *                   single-stream stereo path (1e-4 for a stream's first 0.13 s, 0.06 ulp(trigArg(t)) after; mono sum 2e-6)
  *                   at several times the exact bank's rate.
  * Modes: exact banks cover all four modes (0, 1 integer decimation; 2, 3 the rational resampler convolveBlockResampleFIR,
  * src/filter.cpp:191-223, in its own evaluation order; a block must then end on an output boundary: n_if * upsamp % decim == 0,
- * as the reference's own block sizes do); the fast banks cover modes 0 and 1.
+ * as the reference's own block sizes do), and so do the fast banks: in modes 2 and 3 they run the matrix-core front end (stereo: the fast
+ * band-pass pair and PLL) in front of the same batched resampler (mono, exact = 0, modes 2 / 3: audio within 2e-6 of the reference).
  * Outputs: audio_f32 [n_channels][audio_channels][n_audio] (stereo: left, then right), pcm16
  * [n_channels][n_audio][audio_channels] (stereo: interleaved L,R as the writer at src/project.cpp:292-302). */
 FMRX_API int fmrx_channels_create_ex(fmrx_channels **out, const fmrx_params *p, int n_channels, int audio_channels, int exact,

@@ -511,7 +511,7 @@ class Pipeline:
 
 
 class Channels:
-    """N independent receivers (modes 0/1), the current block of all of them in one device call (fmrx_channels_*).
+    """N independent receivers (all four modes), the current block of all of them in one device call (fmrx_channels_*).
 
     audio_channels: 1 mono, 2 stereo (the reference's second command-line argument).  exact=True: every stage in the
     reference's float32 evaluation order, fmPLL as the serial recurrence with glibc's functions, one lane per channel --

@@ -95,7 +95,7 @@ int fmrx_channels_create_ex(fmrx_channels **out, const fmrx_params *p, int n_cha
     if (!out || !p) return fail(FMRX_EINVAL, "channels_create: null argument");
     if (n_channels < 1) return fail(FMRX_EINVAL, "channels_create: n_channels must be >= 1");
     if (audio_channels != 1 && audio_channels != 2) return fail(FMRX_EINVAL, "channels_create: audio_channels must be 1 (mono) or 2 (stereo)");
-    if (audio_channels == 2 || exact) {
+    if (audio_channels == 2 || exact || p->audio_upsamp != 0) {   // (mono, fast, modes 0/1: the fused-kernel bank below)
         // integer-decimation modes: whole audio samples; resampling modes: the finer rule (n_if * U % D == 0) is checked by the bank
         const size_t unit4 = static_cast<size_t>(2) * p->rf_decim * (p->audio_upsamp ? 1 : p->audio_decim);
         if (block_bytes == 0 || block_bytes % unit4 || block_bytes % 16)
@@ -126,7 +126,6 @@ int fmrx_channels_create_ex(fmrx_channels **out, const fmrx_params *p, int n_cha
         *out = c;
         return FMRX_OK;
     }
-    if (p->audio_upsamp != 0) return fail(FMRX_EINVAL, "channels_create: the batched entry point covers the integer-decimation modes (0, 1)");
     const size_t unit = static_cast<size_t>(2) * p->rf_decim * p->audio_decim;
     if (block_bytes == 0 || block_bytes % unit || block_bytes % 16)
         return fail(FMRX_EINVAL, "channels_create: block_bytes must be a multiple of 16 and of 2*rf_decim*audio_decim = %zu", unit);

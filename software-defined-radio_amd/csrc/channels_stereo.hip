@@ -584,8 +584,8 @@ __global__ __launch_bounds__(64) void chs_out_kernel(const float *__restrict__ d
 // the input samples n_k, n_k - 1, ... with n_k = (k D - ph) / U:  y = sum_j h[ph + j U] x[n_k - j]  (separately rounded products
 // and sums, j ascending), then y += y * U.  A block's outputs restart at phase 0 (the bank accepts blocks with n_if U % D == 0, as
 // the reference's own block sizes are).  The mixer output is materialised here (rows [Hm | n_if], history carried by the finish
-// kernel): the same row serves every output's window.  One thread per (channel, output); the phase rows of the tap table and
-// the windows of neighbouring outputs are L2-resident (this stage is 2 % of the bank's work).
+// kernel): the same row serves every output's window.  chs_resample_exact_kernel: one thread per (channel, output) -- any ratio,
+// and the outputs chs_resample_lanes_kernel (below: the reference's two ratios at 5-7 x its speed) leaves over.
 __global__ void chs_mix_kernel(const float *__restrict__ bpf, const float *__restrict__ nco, long ypitch, const float *__restrict__ nco0,
                                float *__restrict__ mixer, long mpitch, int hm, long k_lo, long k_hi, long wgs_per_channel)
 {
@@ -641,6 +641,179 @@ __global__ void chs_resample_exact_kernel(const float *__restrict__ demod, long 
     }
 }
 
+// The same resampler with the bank turned the other way: a lane is a CHANNEL.  Output k's phase and window position depend on k
+// alone, so for 64 channels at once the taps are wave-uniform -- SGPR operands from a step-major table, as in the exact FIRs
+// above -- and only the samples are per lane.  A wave owns kRS = 7 consecutive outputs of 64 channels at a time (both modes' U are
+// multiples of 7: groups never straddle a period, the table has U / 7 groups) and visits their common window newest sample first:
+// output r meets its taps j ascending (the reference's order, src/filter.cpp:205-212) while one sample per lane and step feeds all
+// seven outputs; (mono, stereo) -- in mono banks two neighbouring outputs -- ride in the two halves of the packed instructions.
+// Samples reach the lanes through LDS, 32 per channel and batch (below: why not lane = channel for the loads too); the taps of
+// four steps are two s_load_dwordx16, requested one iteration ahead.  Outside a group's window the table holds zeros: acc + 0*x
+// leaves acc as it is (acc is never -0: it starts at +0 and sums round to nearest), rows are finite, and the rows' histories
+// are long enough for the window's rounding up to whole batches (StereoBank::res_hist).  Against one thread per (channel,
+// output) -- 101 gathered taps and 101-202 gathered samples per output, bound by the texture addressers -- 16 384 receivers x 4
+// blocks of mode 2: stereo 12 -> 3.2 ms per call, mono 9 -> 1.7 ms (bit-identical outputs).  What bounds it now is the traffic of
+// re-reading the windows: neighbouring groups' windows overlap (160 samples per 38 of advance), and 64 channels' windows of 2-3
+// waves per SIMD do not fit L2.
+constexpr int kRS = 7;
+
+template <bool STEREO, bool EXACT>
+__global__ __launch_bounds__(64) void chs_resample_lanes_kernel(const float *__restrict__ demod, long dpitch, int Hd, const float *__restrict__ mixer,
+                                                                 long mpitch, int hm, int delay, const float *__restrict__ table,
+                                                                 const int *__restrict__ top_of, int groups_per_period, int groups_per_wave,
+                                                                 int iters, int decim, int upsamp, long periods_per_row, int n_channels,
+                                                                 float *__restrict__ audio, int16_t *__restrict__ pcm, int wrap, long a_lo,
+                                                                 long n_out)
+{
+    // workgroup (one wave) = (64 channels, period a_lo / U + `period`, groups [g_lo, g_hi) of that period)
+    // Grid order: channel group fastest, then period, the part of the period slowest -- the waves resident at any moment walk the
+    // SAME groups, whose taps (5 KB per group) then stay in the scalar cache; the whole table (100-300 KB) does not fit there, and
+    // with the part fastest every tap load went to L2 (517 -> 455 us per chunk)
+    const long n_cg = (n_channels + 63) / 64;
+    const long cg = blockIdx.x % n_cg;
+    const long rest = blockIdx.x / n_cg;
+    const long period = rest % periods_per_row;
+    const int g_lo = static_cast<int>(rest / periods_per_row) * groups_per_wave;
+    const int g_hi = g_lo + groups_per_wave < groups_per_period ? g_lo + groups_per_wave : groups_per_period;
+    const int lane = threadIdx.x;
+    const long c_raw = cg * 64 + lane;
+    const long c = c_raw < n_channels ? c_raw : n_channels - 1;     // spare lanes repeat the last channel (nothing stored)
+    const long k_base = a_lo + period * upsamp;                      // first output of this period (a multiple of U: phase 0)
+    const long x_base = k_base / upsamp * decim;                     // its window position
+    const float fu = static_cast<float>(upsamp);
+    typedef float q4 __attribute__((ext_vector_type(4), aligned(4)));   // four consecutive samples of a row, any alignment
+    // Samples reach the lanes through LDS, a batch of kSB = 32 per channel at a time.  Loading them lane = channel (each lane its own
+    // row) makes every load instruction touch 64 cache lines for 1 KiB: the texture addressers, not the ALUs, then set the kernel's
+    // time (804 -> 517 us per chunk).  Instead 8 lanes share a channel's 128 bytes (instruction i: channels 8 i + lane / 8, quad lane % 8):
+    // 8-16 lines per instruction; the quads go to LDS as [sample][channel] rows of 66 floats (lanes of one write hit banks
+    // channel + 8 quad + 2 j: all different), and a step reads its sample for the lane's OWN channel back: consecutive banks.
+    constexpr int kSB = 32, kLP = 66;
+    __shared__ float lds[(STEREO ? 2 : 1) * kSB * kLP];
+    const int sub = lane >> 3, quad = lane & 7;
+    long cl[8];                                                      // the channels this lane loads for (instruction i)
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const long cc = cg * 64 + 8 * i + sub;
+        cl[i] = cc < n_channels ? cc : n_channels - 1;
+    }
+    const long m_off = Hd - delay + x_base, s_off = hm + x_base;     // the all-pass is an index offset
+    for (int g = g_lo; g < g_hi; g++) {
+        const int top = __builtin_amdgcn_readfirstlane(top_of[g]);  // newest sample of the group's window, relative to x_base
+        const uint32_t tbase = static_cast<uint32_t>(g) * static_cast<uint32_t>(iters) * 128u;   // bytes: 4 steps x 8 floats per iteration
+        f2 acc[kRS];
+#pragma unroll
+        for (int r = 0; r < kRS; r++) acc[r] = (f2){0.0f, 0.0f};
+        f16v ta, tb, ua, ub;
+        asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(ta) : "s"(table), "s"(tbase));
+        asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(tb) : "s"(table), "s"(tbase + 64u));
+        q4 gm[8], gs[8];                                             // batch in flight: 8 channels' quads per row
+        // batch bt = samples top - 32 bt - 31 ... top - 32 bt of every channel
+        auto fetch = [&](int bt) __attribute__((always_inline)) {
+            const long first = static_cast<long>(top) - kSB * bt - (kSB - 1) + 4 * quad;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                gm[i] = *reinterpret_cast<const q4 *>(demod + cl[i] * dpitch + m_off + first);
+                if (STEREO) gs[i] = *reinterpret_cast<const q4 *>(mixer + cl[i] * mpitch + s_off + first);
+            }
+        };
+        auto stage = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    lds[(4 * quad + j) * kLP + 8 * i + sub] = gm[i][j];
+                    if (STEREO) lds[kSB * kLP + (4 * quad + j) * kLP + 8 * i + sub] = gs[i][j];
+                }
+        };
+        auto four_steps = [&](int t0, const f16v &h0, const f16v &h1) __attribute__((always_inline)) {
+            float hq[32];
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                hq[q] = h0[q];
+                hq[16 + q] = h1[q];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int sidx = kSB - 1 - (t0 + e);                 // step t of the batch <-> its sample 31 - t (newest first)
+                const float xm = lds[sidx * kLP + lane];
+                const float xs = STEREO ? lds[kSB * kLP + sidx * kLP + lane] : 0.0f;
+                const f2 w = (f2){xm, xs};
+                if constexpr (STEREO) {                              // (mono, stereo) of output r in the two halves
+#pragma unroll
+                    for (int r = 0; r < kRS; r++) {
+                        const float h = hq[8 * e + r];
+                        if constexpr (!EXACT) {
+                            acc[r] = __builtin_elementwise_fma(w, (f2){h, h}, acc[r]);
+                        } else {
+                            const f2 prod = w * (f2){h, h};
+                            acc[r] = acc[r] + prod;
+                        }
+                    }
+                } else {                                             // mono: outputs 2 q, 2 q + 1 in the two halves (the table's eighth tap is 0)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const f2 hh = (f2){hq[8 * e + 2 * q], hq[8 * e + 2 * q + 1]};
+                        if constexpr (!EXACT) {
+                            acc[q] = __builtin_elementwise_fma((f2){xm, xm}, hh, acc[q]);
+                        } else {
+                            const f2 prod = (f2){xm, xm} * hh;
+                            acc[q] = acc[q] + prod;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < kRS; r++) asm volatile("" : "+v"(acc[r]));
+        };
+        const int nb = iters / 8;                                    // batches per group (`iters` is a multiple of 8: host)
+        fetch(0);
+        for (int bt = 0; bt < nb; bt++) {
+            stage();                                                 // (the previous batch's reads are done: one wave, program order)
+            if (bt + 1 < nb) fetch(bt + 1);                          // in flight while this batch is multiplied
+            const uint32_t tb0 = tbase + static_cast<uint32_t>(bt) * 1024u;   // 8 iterations x 128 bytes
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) {
+                // the taps of iteration i + 1 are requested while iteration i runs (the last request of a group reads the next
+                // group's first iteration or the table's pad)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ta), "+s"(tb));
+                asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(ua) : "s"(table), "s"(tb0 + static_cast<uint32_t>(i + 1) * 128u));
+                asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(ub) : "s"(table), "s"(tb0 + static_cast<uint32_t>(i + 1) * 128u + 64u));
+                four_steps(4 * i, ta, tb);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ua), "+s"(ub));
+                asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(ta) : "s"(table), "s"(tb0 + static_cast<uint32_t>(i + 2) * 128u));
+                asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(tb) : "s"(table), "s"(tb0 + static_cast<uint32_t>(i + 2) * 128u + 64u));
+                four_steps(4 * i + 4, ua, ub);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ta), "+s"(tb));   // the look-ahead's loads land before the registers are reused
+        if (c_raw < n_channels) {
+            const long k0 = k_base + static_cast<long>(g) * kRS;
+#pragma unroll
+            for (int r = 0; r < kRS; r++) {
+                const float am = STEREO ? acc[r].x : acc[r / 2][r % 2];
+                const float gm = am * fu;                            // y += y * U  (src/filter.cpp:213)
+                const float mono = am + gm;
+                if constexpr (STEREO) {
+                    const float gs = acc[r].y * fu;
+                    const float st = acc[r].y + gs;
+                    const float l = st + mono, rr = mono - st;       // src/project.cpp:278-279
+                    if (audio) {
+                        audio[c * 2 * n_out + k0 + r] = l;
+                        audio[c * 2 * n_out + n_out + k0 + r] = rr;
+                    }
+                    if (pcm) {
+                        pcm[2 * (c * n_out + k0 + r)] = pcm_pack_flat(l, wrap);
+                        pcm[2 * (c * n_out + k0 + r) + 1] = pcm_pack_flat(rr, wrap);
+                    }
+                } else {
+                    if (audio) audio[c * n_out + k0 + r] = mono;
+                    if (pcm) pcm[c * n_out + k0 + r] = pcm_pack_flat(mono, wrap);
+                }
+            }
+        }
+    }
+}
+
 // carried state: per channel, history <- the slot's last hist_bytes bytes; demod history <- the row's last Hd samples
 // (create() rejects blocks shorter than either history, so source and destination never overlap)
 __global__ void chs_finish_kernel(uint8_t *__restrict__ slots, long slot_bytes, long hist_bytes, float *__restrict__ demod,
@@ -690,6 +863,10 @@ struct StereoBank {
     bool resample = false;
     DevBuf<float> h_res, mixer;
     long mpitch = 0;
+    // ... and, when U is a multiple of 7 (both of the reference's), the step-major tap table of chs_resample_lanes_kernel
+    DevBuf<float> res_table;
+    DevBuf<int> res_top;
+    int res_groups = 0, res_iters = 0, res_hist = 0;   // res_hist: samples of history its windows reach (>= Ha, by the rounding to whole iterations)
     int mix_cur = 0;
     // A stereo call walks the block in chunks on two internal streams: `wide` carries the front end, the band-pass pair and the
     // output stage of every chunk, `lanes` the PLL -- the PLL's few waves (one per 64 channels, a dependent chain each) leave
@@ -826,6 +1003,50 @@ int launch_nco(const StereoBank &b, long k_lo, long k_hi, hipStream_t s)
     return FMRX_OK;
 }
 
+// step-major taps of chs_resample_lanes_kernel: [group of the period][step][8] (7 outputs + pad), steps newest sample first,
+// rounded up to whole iterations of 4 (+ one iteration of zeros that the kernel's look-ahead reads); top_of[group] = the window's
+// newest sample relative to the period's first
+int resample_lanes_table_init(StereoBank &b, const float *h)
+{
+    const int U = b.p.audio_upsamp, D = b.p.audio_decim, T = b.p.audio_taps;
+    if (U <= 0 || U % kRS) return FMRX_OK;                         // other ratios: the one-thread-per-output kernel
+    const int G = U / kRS;
+    std::vector<int> top(G), n_of(U), ph_of(U);
+    int wmax = 0;
+    for (int k = 0; k < U; k++) {
+        const long m = static_cast<long>(k) * D;
+        ph_of[k] = static_cast<int>(m % U);
+        n_of[k] = static_cast<int>((m - ph_of[k]) / U);
+    }
+    for (int g = 0; g < G; g++) {
+        top[g] = n_of[g * kRS + kRS - 1];
+        for (int r = 0; r < kRS; r++) {
+            const int k = g * kRS + r, jmax = (T - 1 - ph_of[k]) / U;   // taps ph, ph + U, ..., ph + jmax U
+            const int w = top[g] - (n_of[k] - jmax) + 1;
+            if (w > wmax) wmax = w;
+        }
+    }
+    const int iters = ((wmax + 3) / 4 + 7) / 8 * 8;                // whole iterations of 4 steps, in batches of 8 (32 samples)
+    // the oldest sample the kernel touches lies 4 iters - 1 behind a group's top: the rows' histories cover it
+    for (int g = 0; g < G; g++)
+        if (4 * iters - 1 - top[g] > b.res_hist) b.res_hist = 4 * iters - 1 - top[g];
+    std::vector<float> tab(static_cast<size_t>(G) * iters * 32 + 32, 0.0f);
+    for (int g = 0; g < G; g++)
+        for (int st = 0; st < 4 * iters; st++)
+            for (int r = 0; r < kRS; r++) {
+                const int k = g * kRS + r, j = n_of[k] - (top[g] - st);
+                const long n = static_cast<long>(ph_of[k]) + static_cast<long>(j) * U;
+                if (j >= 0 && n < T) tab[(static_cast<size_t>(g) * iters * 4 + st) * 8 + r] = h[n];
+            }
+    FMRX_TRY(b.res_table.alloc(tab.size()));
+    FMRX_HIP(hipMemcpy(b.res_table.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    FMRX_TRY(b.res_top.alloc(G));
+    FMRX_HIP(hipMemcpy(b.res_top.p, top.data(), G * sizeof(int), hipMemcpyHostToDevice));
+    b.res_groups = G;
+    b.res_iters = iters;
+    return FMRX_OK;
+}
+
 template <int T, int D>
 int out_table_init(StereoBank &b, const float *h)
 {
@@ -838,6 +1059,44 @@ int out_table_init(StereoBank &b, const float *h)
         }
     FMRX_TRY(b.out_table.alloc(tab.size()));
     FMRX_HIP(hipMemcpy(b.out_table.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    return FMRX_OK;
+}
+
+// convolveBlockResampleFIR for the audio outputs [a_lo, a_hi) of every channel (a_lo: a multiple of U): whole periods by the
+// lane-per-channel kernel when its table exists, what is left (and every other ratio) by one thread per (channel, output)
+template <bool STEREO>
+int launch_resample(StereoBank &b, float *d_audio, int16_t *d_pcm, int wrap, long a_lo, long a_hi, hipStream_t s)
+{
+    const fmrx_params &p = b.p;
+    long done = a_lo;
+    if (b.res_groups > 0 && a_lo % p.audio_upsamp == 0) {
+        const long periods = (a_hi - a_lo) / p.audio_upsamp;
+        if (periods > 0) {
+            const long cgs = (b.n_channels + 63) / 64;
+            // a wave takes `gpw` consecutive groups of a period (neighbouring groups share most of their window): as many as leave
+            // the chip >= 8 waves per SIMD
+            int gpw = b.res_groups;
+            while (gpw > 1 && cgs * periods * ((b.res_groups + gpw - 1) / gpw) < 8192) gpw = (gpw + 1) / 2;
+            const long parts = (b.res_groups + gpw - 1) / gpw;
+            auto go = [&](auto exactc) {
+                hipLaunchKernelGGL((chs_resample_lanes_kernel<STEREO, decltype(exactc)::value>), dim3(static_cast<unsigned>(cgs * periods * parts)),
+                                   dim3(64), 0, s, b.demod.p, b.dpitch, b.Hd, STEREO ? b.mixer.p : nullptr, b.mpitch, b.Hm, b.delay, b.res_table.p,
+                                   b.res_top.p, b.res_groups, gpw, b.res_iters, p.audio_decim, p.audio_upsamp, periods, b.n_channels, d_audio, d_pcm,
+                                   wrap, a_lo, b.n_audio);
+            };
+            if (b.exact) go(std::true_type{});
+            else go(std::false_type{});
+            CHS_LAUNCH_CHECK("chs_resample_lanes_kernel");
+            done = a_lo + periods * p.audio_upsamp;
+        }
+    }
+    if (done < a_hi) {
+        const long wr = (a_hi - done + 255) / 256;
+        hipLaunchKernelGGL(chs_resample_exact_kernel<STEREO>, dim3(static_cast<unsigned>(wr * b.n_channels)), dim3(256), 0, s, b.demod.p, b.dpitch,
+                           b.Hd, STEREO ? b.mixer.p : nullptr, b.mpitch, b.Hm, b.delay, b.h_res.p, p.audio_taps, p.audio_decim, p.audio_upsamp, wr,
+                           d_audio, d_pcm, wrap, done, a_hi, b.n_audio);
+        CHS_LAUNCH_CHECK("chs_resample_exact_kernel");
+    }
     return FMRX_OK;
 }
 
@@ -863,8 +1122,8 @@ void stereo_bank_destroy(StereoBank *b) { delete b; }
 
 int stereo_bank_create(StereoBank **out, const fmrx_params &p, int n_channels, int audio_channels, int exact, size_t block_bytes)
 {
-    if (!exact && audio_channels != 2) return fail(FMRX_EINVAL, "channels: the fast mono bank is fmrx_channels_create's");
-    if (!exact && p.audio_upsamp > 0) return fail(FMRX_EINVAL, "channels: the resampling modes (2, 3) are covered by the exact banks (exact = 1)");
+    if (!exact && audio_channels != 2 && p.audio_upsamp == 0)
+        return fail(FMRX_EINVAL, "channels: the fast mono bank of the integer-decimation modes is fmrx_channels_create's");
     if (!stereo_bank_supported(p, audio_channels))
         return fail(FMRX_EINVAL, "channels (exact): no reference-order kernels for rf %d/%d, audio %d/%d, stereo %d taps (modes 0 and 1 of the "
                     "reference's tap sets are covered)", p.rf_taps, p.rf_decim, p.audio_taps, p.audio_decim, p.stereo_taps);
@@ -895,6 +1154,7 @@ int stereo_bank_create(StereoBank **out, const fmrx_params &p, int n_channels, i
         if (b->resample) {
             FMRX_TRY(b->h_res.alloc(p.audio_taps));
             FMRX_HIP(hipMemcpy(b->h_res.p, ha.data(), p.audio_taps * sizeof(float), hipMemcpyHostToDevice));
+            FMRX_TRY(resample_lanes_table_init(*b, ha.data()));
         } else {
 #define X(T_, D_) if (p.audio_taps == T_ && p.audio_decim == D_) FMRX_TRY((out_table_init<T_, D_>(*b, ha.data())));
             CHS_OUT_CASES(X)
@@ -911,8 +1171,10 @@ int stereo_bank_create(StereoBank **out, const fmrx_params &p, int n_channels, i
         b->delay = audio_channels == 2 ? (p.stereo_taps - 1) / 2 : 0;                        // allPass, src/filter.cpp:14-29
         b->Hd = b->Ha + b->delay;
         if (audio_channels == 2 && b->St - 1 + 3 > b->Hd) b->Hd = b->St - 1 + 3;
+        const int more = b->res_hist > b->Ha ? b->res_hist - b->Ha : 0;   // (the lane-per-channel resampler rounds its windows up to whole iterations)
+        if (b->Ha + b->delay + more > b->Hd) b->Hd = b->Ha + b->delay + more;
         b->Hd = (b->Hd + 3) / 4 * 4 + 4;
-        b->Hm = (b->Ha + 3) / 4 * 4 + 4;
+        b->Hm = (b->Ha + more + 3) / 4 * 4 + 4;
         if (block_bytes < b->hist_bytes || b->n_if < b->Hd)
             return fail(FMRX_EINVAL, "channels (exact): block of %zu bytes is shorter than the history a channel carries (%zu bytes, %d IF samples)",
                         block_bytes, b->hist_bytes, b->Hd);
@@ -1041,14 +1303,11 @@ int stereo_bank_process_dev(StereoBank *b, float *d_audio, int16_t *d_pcm, int w
         auto if_of = [&](long a) -> long { return b->resample ? a / p.audio_upsamp * p.audio_decim : a * p.audio_decim; };
         auto out = [&](long a_lo, long a_hi, long g_hi, hipStream_t st) -> int {
             if (b->resample) {
-                const long k_lo = if_of(a_lo), wm = (g_hi - k_lo + 255) / 256, wr = (a_hi - a_lo + 255) / 256;
+                const long k_lo = if_of(a_lo), wm = (g_hi - k_lo + 255) / 256;
                 hipLaunchKernelGGL(chs_mix_kernel, dim3(static_cast<unsigned>(wm * b->n_channels)), dim3(256), 0, st, b->bpf.p, b->trig.p, b->ypitch,
                                    b->nco0.p, b->mixer.p, b->mpitch, b->Hm, k_lo, g_hi, wm);
-                hipLaunchKernelGGL(chs_resample_exact_kernel<true>, dim3(static_cast<unsigned>(wr * b->n_channels)), dim3(256), 0, st, b->demod.p,
-                                   b->dpitch, b->Hd, b->mixer.p, b->mpitch, b->Hm, b->delay, b->h_res.p, p.audio_taps, p.audio_decim,
-                                   p.audio_upsamp, wr, d_audio, d_pcm, wrap, a_lo, a_hi, b->n_audio);
-                CHS_LAUNCH_CHECK("chs_resample_exact_kernel");
-                return FMRX_OK;
+                CHS_LAUNCH_CHECK("chs_mix_kernel");
+                return launch_resample<true>(*b, d_audio, d_pcm, wrap, a_lo, a_hi, st);
             }
 #define X(T_, D_) if (p.audio_taps == T_ && p.audio_decim == D_) return launch_out<T_, D_, true>(*b, d_audio, d_pcm, wrap, a_lo, a_hi, g_hi, st);
             CHS_OUT_CASES(X)
@@ -1132,7 +1391,8 @@ int stereo_bank_process_dev(StereoBank *b, float *d_audio, int16_t *d_pcm, int w
             if (c >= lag) {   // the output stage of an earlier chunk, behind this chunk's band-pass pair on the wide stream
                 const long a_lo = (c - lag) * per, a_hi = a_lo + per < b->n_audio ? a_lo + per : b->n_audio;
                 if (K > 1) FMRX_HIP(hipStreamWaitEvent(so, b->ev_pll[c - lag], 0));   // (the PLL followed this chunk's band-pass pair: both are done)
-                if (b->exact) FMRX_TRY(launch_nco(*b, if_of(a_lo), if_of(a_hi), so));   // fast banks: inside the output stage
+                // fast banks, modes 0/1: inside the output stage; the resampling modes materialise the mixer rows from finished NCO values
+                if (b->exact || b->resample) FMRX_TRY(launch_nco(*b, if_of(a_lo), if_of(a_hi), so));
                 FMRX_TRY(out(a_lo, a_hi, if_of(a_hi), so));
             }
         }
@@ -1144,11 +1404,7 @@ int stereo_bank_process_dev(StereoBank *b, float *d_audio, int16_t *d_pcm, int w
     } else {
         FMRX_TRY(fe(0, b->n_if, s));
         if (b->resample) {
-            const long wr = (b->n_audio + 255) / 256;
-            hipLaunchKernelGGL(chs_resample_exact_kernel<false>, dim3(static_cast<unsigned>(wr * b->n_channels)), dim3(256), 0, s, b->demod.p,
-                               b->dpitch, b->Hd, nullptr, 0L, 0, b->delay, b->h_res.p, p.audio_taps, p.audio_decim, p.audio_upsamp, wr, d_audio,
-                               d_pcm, wrap, 0L, b->n_audio, b->n_audio);
-            CHS_LAUNCH_CHECK("chs_resample_exact_kernel");
+            FMRX_TRY(launch_resample<false>(*b, d_audio, d_pcm, wrap, 0, b->n_audio, s));
         } else {
 #define X(T_, D_) if (p.audio_taps == T_ && p.audio_decim == D_) FMRX_TRY((launch_out<T_, D_, false>(*b, d_audio, d_pcm, wrap, 0, b->n_audio, b->n_if, s)));
             CHS_OUT_CASES(X)
@@ -1185,7 +1441,7 @@ int stereo_bank_read_tap(StereoBank *b, int channel, int which, float *out, size
     if (which == FMRX_TAP_PLL) {
         FMRX_HIP(hipMemcpy(out, b->nco0.p + channel, sizeof(float), hipMemcpyDeviceToHost));
         FMRX_HIP(hipMemcpy(out + 1, src, n_if * sizeof(float), hipMemcpyDeviceToHost));
-        if (!b->exact)   // the fast bank keeps the raw trigArg of every step (the cosine is taken inside the output stage)
+        if (!b->exact && !b->resample)   // the fast bank of modes 0/1 keeps the raw trigArg of every step (the cosine is taken inside the output stage)
             for (size_t k = 1; k <= n_if; k++) out[k] = std::cos(out[k] * 2.0f + 0.0f);
         return FMRX_OK;
     }

@@ -102,8 +102,6 @@ def test_bank_other_block_sizes(fmrx, oracle):
     with pytest.raises(fmrx.FmrxError):
         fmrx.Channels(0, 4, audio_channels=2, exact=True, block_bytes=1600)      # shorter than the history a channel carries
     with pytest.raises(fmrx.FmrxError):
-        fmrx.Channels(2, 4, audio_channels=2, exact=False)                       # resampling modes: exact banks only
-    with pytest.raises(fmrx.FmrxError):
         fmrx.Channels(2, 4, audio_channels=2, exact=True, block_bytes=16160)     # 808 IF samples: a block must end on an output boundary (n_if * U % D == 0)
 
 
@@ -150,9 +148,60 @@ def test_stereo_bank_fast_error_envelope(fmrx, oracle, fused):
     print(f"fast stereo bank: worst window error over {N} channels = {worst:.3f} ulp(trigArg)")
 
 
+@pytest.mark.parametrize("mode", [2, 3])
+def test_bank_fast_resampling_modes(fmrx, oracle, mode):
+    """The fast banks in the resampling modes (44.1 kHz out; src/project.cpp:425-426): matrix-core front end, the band-pass pair
+    and the PLL of the fast stereo bank, mixer rows and the batched reference-order resampler (src/filter.cpp:191-223).
+    Mono (exact = 0 routes the resampling modes to this bank): audio RMS error <= 1e-4 (measured ~1e-7), s16 equal or +-1 LSB.
+    Stereo: the default path's envelope per receiver and 0.1 s window, mono sum <= 2e-6."""
+    from test_gpu_parity import ENVELOPE_FACTOR, stereo_error_envelope, trig_arg_ulp
+    p = oracle.mode_params(mode, 101, 101, 101)
+    bb = p.block_bytes
+    # mono
+    N, nblk = 5, 3
+    streams = [channel_stream(oracle, c, bb // 2 * nblk, p.rf_Fs) for c in range(N)]
+    ch = fmrx.Channels(mode, N)                                   # audio_channels = 1, exact = 0
+    refs = [oracle.pipeline(mode, 1) for _ in range(N)]
+    for b in range(nblk):
+        out = ch.process(np.stack([st[b * bb:(b + 1) * bb] for st in streams]))
+        for c in range(N):
+            want = refs[c].process(streams[c][b * bb:(b + 1) * bb])["audio"]
+            err = float(np.sqrt(np.mean((out["audio"][c].astype(np.float64) - want) ** 2)))
+            assert err <= 1e-4 and err <= 2e-6, (mode, c, b, err)
+            assert np.abs(out["pcm16"][c].astype(np.int32) - oracle.pcm16(want).astype(np.int32)).max() <= 1
+    ch.close()
+    # stereo: 0.5 s per receiver
+    N, nblk = 6, int(0.5 * p.rf_Fs / (bb // 2)) + 1
+    with ProcessPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+        res = sorted(ex.map(_oracle_channel, [(c, nblk, bb, float(p.rf_Fs), mode) for c in range(N)]), key=lambda r: r[0])
+    ch = fmrx.Channels(mode, N, audio_channels=2, exact=False)
+    na = ch.n_audio
+    L = np.zeros((N, nblk * na), np.float32)
+    R = np.zeros((N, nblk * na), np.float32)
+    for b in range(nblk):
+        out = ch.process(np.stack([r[1][b * bb:(b + 1) * bb] for r in res]), want_pcm=False)
+        L[:, b * na:(b + 1) * na] = out["audio_l"]
+        R[:, b * na:(b + 1) * na] = out["audio_r"]
+    win = 4410
+    t_end = (np.arange(nblk * na // win) + 1) * 0.1
+    ulp = trig_arg_ulp(t_end, if_Fs=float(p.if_Fs))
+    bound = np.maximum(1e-4, ENVELOPE_FACTOR * ulp)
+    worst = 0.0
+    for c in range(N):
+        for got, want in ((L[c], res[c][2]), (R[c], res[c][3])):
+            env = stereo_error_envelope(got, want, win)
+            assert (env <= bound).all(), (mode, c, env, bound)
+            assert env[0] <= 1e-4
+            worst = max(worst, float((env / ulp).max()))
+        mono = stereo_error_envelope((L[c].astype(np.float64) + R[c]) / 2, (res[c][2].astype(np.float64) + res[c][3]) / 2, win)
+        assert mono.max() <= 2e-6, (mode, c, mono.max())
+    print(f"fast stereo bank, mode {mode}: worst window error over {N} receivers = {worst:.3f} ulp(trigArg)")
+
+
 def _oracle_channel(args):
     """Worker: channel c's stream and the oracle's left / right over it (CPU, one process per channel)."""
-    c, nblk, bb, rf_Fs = args
+    c, nblk, bb, rf_Fs = args[:4]
+    mode = args[4] if len(args) > 4 else 0
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     if here not in sys.path:
@@ -160,7 +209,7 @@ def _oracle_channel(args):
     from _oracle import Oracle
     o = Oracle()
     iq = channel_stream(o, c, bb // 2 * nblk, rf_Fs)
-    pl = o.pipeline(0, 2)
+    pl = o.pipeline(mode, 2)
     L, R = [], []
     for b in range(nblk):
         out = pl.process(iq[b * bb:(b + 1) * bb])
