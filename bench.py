@@ -132,7 +132,7 @@ def cpu_baseline(seconds: float = 10.0) -> dict:
     n2, t2 = run_two_threads(seconds * 0.3)
     per_mode = {"mode1_mono": run_mode(1, 1, seconds * 0.3), "mode2_mono": run_mode(2, 1, seconds * 0.3),
                 "mode3_mono": run_mode(3, 1, seconds * 0.3), "mode0_stereo": run_mode(0, 2, seconds * 0.3),
-                "mode1_stereo": run_mode(1, 2, seconds * 0.2)}
+                "mode1_stereo": run_mode(1, 2, seconds * 0.2), "mode2_stereo": run_mode(2, 2, seconds * 0.2)}
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(cores, 64))
     with ThreadPoolExecutor(cores) as ex:                # ctypes releases the GIL inside the C call
@@ -405,32 +405,37 @@ def side_legs(torch, fmrx, synth, args, pl, step, d_iq, n_bytes, stream) -> dict
     except Exception as e:
         legs["mode0_stereo_exact"] = {"error": str(e)}
     #      many streams: the receiver bank, one lane per channel walks the exact recurrence (fmrx_channels_create_ex, exact = 1)
-    def bank_leg(name, mode, nch, blocks_per_call, calls, exact=True):
+    def bank_leg(name, mode, nch, blocks_per_call, calls, exact=True, audio_channels=2):
         p = fmrx.modeParams(mode)
         bb = int(p.block_bytes) * blocks_per_call
         ns = bb // 2
         distinct = 64                                          # distinct signals dealt round-robin over the channels: every lane of a wave differs
         base = torch.stack([torch.from_numpy(synth.synth_fm_u8(ns, float(p.rf_Fs), seed=0x3D74 + c, start=7919 * c)) for c in range(distinct)]).cuda()
-        chs = fmrx.Channels(mode, nch, audio_channels=2, exact=exact, block_bytes=bb, device=torch.cuda.current_device())
+        chs = fmrx.Channels(mode, nch, audio_channels=audio_channels, exact=exact, block_bytes=bb, device=torch.cuda.current_device())
         src = base.repeat((nch + distinct - 1) // distinct, 1)[:nch].contiguous()
         chs.load_dev(src.data_ptr(), stream)
         del src, base
-        d_pcm_all = torch.empty(nch * chs.n_audio * 2, dtype=torch.int16, device="cuda")
+        d_pcm_all = torch.empty(nch * chs.n_audio * audio_channels, dtype=torch.int16, device="cuda")
         ms = event_ms(torch, lambda: chs.process_dev(None, d_pcm_all.data_ptr(), wrap=True, stream=stream), calls, warm=2)
         how = ("fmrx_channels_create_ex(exact = 1): reference evaluation order in every stage, fmPLL one lane per channel with glibc's sinf/cosf/atan2f"
                if exact else
                "fmrx_channels_create_ex(exact = 0): matrix-core front end, one fma per tap in the band-pass pair and the audio FIRs, the PLL's fast "
                "recurrence one lane per channel, three internal streams")
-        nm, d = leg(name, f"{nch} independent mode-{mode} STEREO receivers, {ns:,} samples ({blocks_per_call} reference block(s)) each per call, "
-                    f"{how}; s16 L,R out; inputs resident in HBM, 64 distinct signals dealt over the channels", nch * ns, ms,
-                    2.0 + 4.0 / (p.rf_decim * p.audio_decim))
-        d["tolerance"] = TOL_EXACT if exact else TOL_FAST
+        out_rate = (p.audio_upsamp / float(p.audio_decim) if p.audio_upsamp else 1.0 / p.audio_decim) / p.rf_decim   # audio samples per input sample
+        if audio_channels == 1 and not exact:
+            how = "fmrx_channels_create_ex(audio_channels = 1, exact = 0), resampling mode: matrix-core front end + the batched lane-per-channel resampler"
+        nm, d = leg(name, f"{nch} independent mode-{mode} {'STEREO' if audio_channels == 2 else 'MONO'} receivers, {ns:,} samples ({blocks_per_call} reference "
+                    f"block(s)) each per call, {how}; s16 {'L,R ' if audio_channels == 2 else ''}out; inputs resident in HBM, 64 distinct signals dealt over "
+                    f"the channels", nch * ns, ms, 2.0 + 2.0 * audio_channels * out_rate)
+        d["tolerance"] = TOL_EXACT if exact else (TOL_FAST if audio_channels == 2 else "audio RMS error vs the reference <= 2e-6 (north star: 1e-4)")
         d["channels"] = nch
         d["channels_at_real_time"] = int(nch * (ns / float(p.rf_Fs)) / (ms * 1e-3))
         d["bound"] = (("vector ALU, not HBM: the reference's order is 2 separately rounded vector operations per tap and output (nothing for the matrix "
                        "cores), ~83 lane-instructions per input sample in total; frac is reported on the HBM peak for comparability only") if exact else
                       ("HBM traffic of the float32 intermediates between its five kernels (5.5 B per input sample against 2.08 algorithmic) and the "
-                       "vector ALUs of the band-pass pair; DESIGN.md 4.7"))
+                       "vector ALUs of the band-pass pair; DESIGN.md 4.7") if audio_channels == 2 else
+                      ("front end: HBM (2.4 B per input sample with the discriminator's round trip); resampler: re-reading its overlapping windows; "
+                       "DESIGN.md 4.7"))
         legs[nm] = d
         chs.close()
         del chs, d_pcm_all
@@ -440,6 +445,8 @@ def side_legs(torch, fmrx, synth, args, pl, step, d_iq, n_bytes, stream) -> dict
         bank_leg("stereo_channels_exact", 0, 16384, 4, 3)
         bank_leg("stereo_channels_exact_65536", 0, 65536, 1, 3)
         bank_leg("stereo_channels_exact_mode1", 1, 16384, 4, 3)
+        bank_leg("stereo_channels_exact_mode2", 2, 16384, 4, 3)        # 44.1 kHz out: the batched reference-order resampler behind the PLL
+        bank_leg("mono_channels_mode2", 2, 16384, 4, 3, exact=False, audio_channels=1)
     except Exception as e:
         legs["stereo_channels_exact_error"] = {"error": str(e)}
     # (5) a live channel's regime: reference-size blocks (51,200 samples), one call per block, device-resident

@@ -59,8 +59,10 @@ def test_bench_json_contract(fmrx):
     bank = out["legs"]["stereo_channels_exact"]
     assert bank["tolerance"].startswith("bit-exact") and bank["value"] > 1e4 and bank["channels"] >= 256
     assert out["legs"]["stereo_channels"]["value"] > bank["value"] and "ulp(trigArg" in out["legs"]["stereo_channels"]["tolerance"]
+    assert out["legs"]["stereo_channels_exact_mode2"]["tolerance"].startswith("bit-exact") and out["legs"]["stereo_channels_exact_mode2"]["value"] > 1e4
+    assert out["legs"]["mono_channels_mode2"]["value"] > 1e4 and "2e-6" in out["legs"]["mono_channels_mode2"]["tolerance"]
     # the CPU figure beside every mode's leg
-    for k in ("mode1_mono", "mode2_mono", "mode3_mono", "mode0_stereo"):
+    for k in ("mode1_mono", "mode2_mono", "mode3_mono", "mode0_stereo", "mode2_stereo"):
         assert c["legs"][k]["value"] > 0.5 and c["legs"][k]["cores"] == 1
     # the line says which library was timed
     lib = out["config"]["library"]
