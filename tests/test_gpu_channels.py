@@ -83,6 +83,28 @@ def test_mono_bank_exact(fmrx, oracle):
                 bits_equal(out["pcm16"][c], oracle.pcm16(want))
 
 
+def test_bank_resampler_channel_groups(fmrx, oracle):
+    """The lane-per-channel resampler works on groups of 64 channels (8 lanes share a channel's loads; spare lanes repeat the last
+    channel): a bank of 65 receivers -- one full group and one with a single member -- in mode 2, stereo and mono, bit for bit."""
+    p = oracle.mode_params(2, 101, 101, 101)
+    N, nblk, bb = 65, 2, p.block_bytes
+    base = [channel_stream(oracle, c, bb // 2 * nblk, p.rf_Fs) for c in range(3)]
+    streams = [base[c % 3] for c in range(N)]
+    for st in (2, 1):
+        ch = fmrx.Channels(2, N, audio_channels=st, exact=True)
+        refs = [oracle.pipeline(2, st) for _ in range(3)]
+        for b in range(nblk):
+            out = ch.process(np.stack([s_[b * bb:(b + 1) * bb] for s_ in streams]), want_pcm=False)
+            want = [refs[c].process(base[c][b * bb:(b + 1) * bb]) for c in range(3)]
+            for c in (0, 1, 2, 62, 63, 64):
+                if st == 2:
+                    bits_equal(out["audio_l"][c], want[c % 3]["audio_l"], f"stereo channel {c} block {b}")
+                    bits_equal(out["audio_r"][c], want[c % 3]["audio_r"], f"stereo channel {c} block {b}")
+                else:
+                    bits_equal(out["audio"][c], want[c % 3]["audio"], f"mono channel {c} block {b}")
+        ch.close()
+
+
 def test_bank_other_block_sizes(fmrx, oracle):
     """Blocks that are not the reference's size: ragged against the kernels' tiles (504 IF outputs per wave, 2048 per
     band-pass workgroup, 512 audio outputs per workgroup), several times the reference's, and the smallest the bank
