@@ -330,7 +330,8 @@ __global__ __launch_bounds__(64) void chs_bpf_kernel(const float *__restrict__ d
 // (glibc's cosf: the branch-free form when the whole wave's arguments are ordinary, i.e. always but in a stream's first 120 samples).
 template <bool EXACT>
 __global__ __launch_bounds__(256) void chs_nco_kernel(float *__restrict__ trig, long ypitch, long k_lo, long k_hi, long wgs_per_channel,
-                                                             float nco_scale, float phase_adjust)
+                                                             float nco_scale, float phase_adjust, const float *__restrict__ bpf,
+                                                             const float *__restrict__ nco0, float *__restrict__ mixer, long mpitch, int hm)
 {
     __shared__ uint32_t w24[24];
     if (threadIdx.x < 24) w24[threadIdx.x] = glibc235::inv_pio4(threadIdx.x);
@@ -368,6 +369,17 @@ __global__ __launch_bounds__(256) void chs_nco_kernel(float *__restrict__ trig, 
 #pragma unroll
         for (int i = 0; i < 4; i++)
             if (k + i < k_hi) trig[c * ypitch + k + i] = o[i];
+    }
+    // The resampling modes read the mixer output (src/project.cpp:246-248: (stereo_filt * PLL) * 2, PLL[g] = the NCO value of step
+    // g - 1, PLL[0] = the incoming state's lastOut) as a row of its own (chs_resample_*): written here, rows [hm | n_if], history
+    // carried by the finish kernel.  Entry k_lo takes the NCO value the previous chunk's launch left in trig[k_lo - 1].
+    if (mixer) {
+        const float *bp = bpf + c * ypitch;
+        float *mx = mixer + c * mpitch + hm;
+        if (k == k_lo) mx[k] = (bp[k] * (k > 0 ? trig[c * ypitch + k - 1] : nco0[c])) * 2.0f;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (k + 1 + i < k_hi) mx[k + 1 + i] = (bp[k + 1 + i] * o[i]) * 2.0f;
     }
 }
 
@@ -583,19 +595,9 @@ __global__ __launch_bounds__(64) void chs_out_kernel(const float *__restrict__ d
 // all-passed discriminator output and on the mixer output.  In stream form: output k reads phase ph = (k D) mod U of the taps and
 // the input samples n_k, n_k - 1, ... with n_k = (k D - ph) / U:  y = sum_j h[ph + j U] x[n_k - j]  (separately rounded products
 // and sums, j ascending), then y += y * U.  A block's outputs restart at phase 0 (the bank accepts blocks with n_if U % D == 0, as
-// the reference's own block sizes are).  The mixer output is materialised here (rows [Hm | n_if], history carried by the finish
-// kernel): the same row serves every output's window.  chs_resample_exact_kernel: one thread per (channel, output) -- any ratio,
+// the reference's own block sizes are).  The mixer output is materialised by the chunk's NCO pass (chs_nco_kernel; rows [Hm | n_if],
+// history carried by the finish kernel): the same row serves every output's window.  chs_resample_exact_kernel: one thread per (channel, output) -- any ratio,
 // and the outputs chs_resample_lanes_kernel (below: the reference's two ratios at 5-7 x its speed) leaves over.
-__global__ void chs_mix_kernel(const float *__restrict__ bpf, const float *__restrict__ nco, long ypitch, const float *__restrict__ nco0,
-                               float *__restrict__ mixer, long mpitch, int hm, long k_lo, long k_hi, long wgs_per_channel)
-{
-    const long c = blockIdx.x / wgs_per_channel;
-    const long k = k_lo + (blockIdx.x % wgs_per_channel) * 256 + threadIdx.x;
-    if (k >= k_hi) return;
-    const float pll = k > 0 ? nco[c * ypitch + k - 1] : nco0[c];               // PLL[k]; PLL[0] = the incoming state's lastOut
-    mixer[c * mpitch + hm + k] = (bpf[c * ypitch + k] * pll) * 2.0f;           // (stereo_filt * PLL) * 2, src/project.cpp:246-248
-}
-
 template <bool STEREO>
 __global__ void chs_resample_exact_kernel(const float *__restrict__ demod, long dpitch, int Hd, const float *__restrict__ mixer, long mpitch,
                                           int hm, int delay, const float *__restrict__ h, int taps, int decim, int upsamp,
@@ -995,10 +997,10 @@ int launch_nco(const StereoBank &b, long k_lo, long k_hi, hipStream_t s)
     const long wgs = (k_hi - k_lo + 1023) / 1024;
     if (b.exact)
         hipLaunchKernelGGL(chs_nco_kernel<true>, dim3(static_cast<unsigned>(wgs * b.n_channels)), dim3(256), 0, s, b.trig.p, b.ypitch, k_lo, k_hi,
-                           wgs, 2.0f, 0.0f);
+                           wgs, 2.0f, 0.0f, b.bpf.p, b.nco0.p, b.resample ? b.mixer.p : nullptr, b.mpitch, b.Hm);
     else
         hipLaunchKernelGGL(chs_nco_kernel<false>, dim3(static_cast<unsigned>(wgs * b.n_channels)), dim3(256), 0, s, b.trig.p, b.ypitch, k_lo, k_hi,
-                           wgs, 2.0f, 0.0f);
+                           wgs, 2.0f, 0.0f, b.bpf.p, b.nco0.p, b.resample ? b.mixer.p : nullptr, b.mpitch, b.Hm);
     CHS_LAUNCH_CHECK("chs_nco_kernel");
     return FMRX_OK;
 }
@@ -1303,10 +1305,7 @@ int stereo_bank_process_dev(StereoBank *b, float *d_audio, int16_t *d_pcm, int w
         auto if_of = [&](long a) -> long { return b->resample ? a / p.audio_upsamp * p.audio_decim : a * p.audio_decim; };
         auto out = [&](long a_lo, long a_hi, long g_hi, hipStream_t st) -> int {
             if (b->resample) {
-                const long k_lo = if_of(a_lo), wm = (g_hi - k_lo + 255) / 256;
-                hipLaunchKernelGGL(chs_mix_kernel, dim3(static_cast<unsigned>(wm * b->n_channels)), dim3(256), 0, st, b->bpf.p, b->trig.p, b->ypitch,
-                                   b->nco0.p, b->mixer.p, b->mpitch, b->Hm, k_lo, g_hi, wm);
-                CHS_LAUNCH_CHECK("chs_mix_kernel");
+                (void)g_hi;   // the mixer rows of this chunk were written by its NCO pass (launch_nco)
                 return launch_resample<true>(*b, d_audio, d_pcm, wrap, a_lo, a_hi, st);
             }
 #define X(T_, D_) if (p.audio_taps == T_ && p.audio_decim == D_) return launch_out<T_, D_, true>(*b, d_audio, d_pcm, wrap, a_lo, a_hi, g_hi, st);
