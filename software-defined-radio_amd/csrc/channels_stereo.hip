@@ -1439,9 +1439,21 @@ int stereo_bank_read_tap(StereoBank *b, int channel, int which, float *out, size
     if (!out) return FMRX_OK;
     if (which == FMRX_TAP_PLL) {
         FMRX_HIP(hipMemcpy(out, b->nco0.p + channel, sizeof(float), hipMemcpyDeviceToHost));
+        if (!b->exact && !b->resample) {
+            // the fast bank of modes 0/1 keeps the raw trigArg of every step (the cosine is taken inside the output stage): the same
+            // NCO pass the other banks run, here on a copy of the one row
+            DevBuf<float> tmp;
+            const long pitch = (static_cast<long>(n_if) + 16 + 3) / 4 * 4;
+            FMRX_TRY(tmp.alloc(static_cast<size_t>(pitch)));
+            FMRX_HIP(hipMemcpy(tmp.p, src, n_if * sizeof(float), hipMemcpyDeviceToDevice));
+            const long wgs = (static_cast<long>(n_if) + 1023) / 1024;
+            hipLaunchKernelGGL(chs_nco_kernel<false>, dim3(static_cast<unsigned>(wgs)), dim3(256), 0, nullptr, tmp.p, pitch, 0L, static_cast<long>(n_if),
+                               wgs, 2.0f, 0.0f, nullptr, nullptr, nullptr, 0L, 0);
+            CHS_LAUNCH_CHECK("chs_nco_kernel");
+            FMRX_HIP(hipMemcpy(out + 1, tmp.p, n_if * sizeof(float), hipMemcpyDeviceToHost));
+            return FMRX_OK;
+        }
         FMRX_HIP(hipMemcpy(out + 1, src, n_if * sizeof(float), hipMemcpyDeviceToHost));
-        if (!b->exact && !b->resample)   // the fast bank of modes 0/1 keeps the raw trigArg of every step (the cosine is taken inside the output stage)
-            for (size_t k = 1; k <= n_if; k++) out[k] = std::cos(out[k] * 2.0f + 0.0f);
         return FMRX_OK;
     }
     FMRX_HIP(hipMemcpy(out, src, cnt * sizeof(float), hipMemcpyDeviceToHost));

@@ -151,6 +151,11 @@ def test_stereo_bank_fast_error_envelope(fmrx, oracle, fused):
         L[:, b * 1024:(b + 1) * 1024] = out["audio_l"]
         R[:, b * 1024:(b + 1) * 1024] = out["audio_r"]
         if b == 0:
+            # the fast bank's NCO tap (it keeps trigArg; the tap runs the NCO pass on a copy of the row): n_if + 1 values, PLL[0] = the
+            # incoming state's lastOut, a 38 kHz cosine after lock
+            nco = ch.read_tap(3, "pll")
+            assert len(nco) == bb // 2 // p.rf_decim + 1 and nco[0] == 1.0 and np.isfinite(nco).all() and np.abs(nco).max() <= 1.0
+            assert 0.4 < float(np.sqrt(np.mean(nco[1000:].astype(np.float64) ** 2))) < 0.9
             # the s16 output is the pack of the float output (what is compared with the reference below)
             for c in range(N):
                 bits_equal(out["pcm16"][c, :, 0], oracle.pcm16(out["audio_l"][c]), f"pcm left, channel {c}")
