@@ -656,13 +656,15 @@ __global__ void chs_resample_exact_kernel(const float *__restrict__ demod, long 
 // output) -- 101 gathered taps and 101-202 gathered samples per output, bound by the texture addressers -- 16 384 receivers x 4
 // blocks of mode 2: stereo 12 -> 3.2 ms per call, mono 9 -> 1.7 ms (bit-identical outputs).  What bounds it now is the traffic of
 // re-reading the windows: neighbouring groups' windows overlap (160 samples per 38 of advance), and 64 channels' windows of 2-3
-// waves per SIMD do not fit L2.  The kRW = 3 waves of a workgroup therefore take three NEIGHBOURING groups at the same time
-// (each with its own staging area, no barrier): their loads meet in L1 / L2 (mono fast, mode 2: 3.6 -> 3.4 ms per call).
+// waves per SIMD do not fit L2.  The kRW = 3 (mono: 7) waves of a workgroup therefore take NEIGHBOURING groups at the same time
+// (each with its own staging area, no barrier): their loads meet in L1 / L2 (mono fast, mode 2: 3.6 -> 3.4 ms per call with 3 waves, 3.0
+// with 7; stereo banks stage twice as much per wave and 7 waves leave one workgroup per CU: no gain over 3).
 constexpr int kRS = 7;
-constexpr int kRW = 3;   // waves per workgroup: they take neighbouring groups (overlapping windows) at the same time
+// waves per workgroup: they take neighbouring groups (overlapping windows) at the same time; mono banks stage half as much per wave
+template <bool STEREO> constexpr int kRW = STEREO ? 3 : 7;
 
 template <bool STEREO, bool EXACT>
-__global__ __launch_bounds__(64 * kRW) void chs_resample_lanes_kernel(const float *__restrict__ demod, long dpitch, int Hd, const float *__restrict__ mixer,
+__global__ __launch_bounds__(64 * kRW<STEREO>) void chs_resample_lanes_kernel(const float *__restrict__ demod, long dpitch, int Hd, const float *__restrict__ mixer,
                                                                  long mpitch, int hm, int delay, const float *__restrict__ table,
                                                                  const int *__restrict__ top_of, int groups_per_period, int groups_per_wave,
                                                                  int iters, int decim, int upsamp, long periods_per_row, int n_channels,
@@ -692,7 +694,7 @@ __global__ __launch_bounds__(64 * kRW) void chs_resample_lanes_kernel(const floa
     // 8-16 lines per instruction; the quads go to LDS as [sample][channel] rows of 66 floats (lanes of one write hit banks
     // channel + 8 quad + 2 j: all different), and a step reads its sample for the lane's OWN channel back: consecutive banks.
     constexpr int kSB = 32, kLP = 66;
-    __shared__ float lds_all[kRW * (STEREO ? 2 : 1) * kSB * kLP];
+    __shared__ float lds_all[kRW<STEREO> * (STEREO ? 2 : 1) * kSB * kLP];
     float *lds = lds_all + wv * ((STEREO ? 2 : 1) * kSB * kLP);   // a wave's own staging area: no barriers
     const int sub = lane >> 3, quad = lane & 7;
     long cl[8];                                                      // the channels this lane loads for (instruction i)
@@ -702,7 +704,7 @@ __global__ __launch_bounds__(64 * kRW) void chs_resample_lanes_kernel(const floa
         cl[i] = cc < n_channels ? cc : n_channels - 1;
     }
     const long m_off = Hd - delay + x_base, s_off = hm + x_base;     // the all-pass is an index offset
-    for (int g = g_lo + wv; g < g_hi; g += kRW) {
+    for (int g = g_lo + wv; g < g_hi; g += kRW<STEREO>) {
         const int top = __builtin_amdgcn_readfirstlane(top_of[g]);  // newest sample of the group's window, relative to x_base
         const uint32_t tbase = static_cast<uint32_t>(g) * static_cast<uint32_t>(iters) * 128u;   // bytes: 4 steps x 8 floats per iteration
         f2 acc[kRS];
@@ -1081,12 +1083,13 @@ int launch_resample(StereoBank &b, float *d_audio, int16_t *d_pcm, int wrap, lon
             // a wave takes `gpw` consecutive groups of a period (neighbouring groups share most of their window): as many as leave
             // the chip >= 8 waves per SIMD
             int gpw = b.res_groups;
-            while (gpw > kRW && cgs * periods * ((b.res_groups + gpw - 1) / gpw) * kRW < 8192) gpw = (gpw + 1) / 2;
-            gpw = (gpw + kRW - 1) / kRW * kRW;                     // every wave of a workgroup gets a group
+            constexpr int NW = kRW<STEREO>;
+            while (gpw > NW && cgs * periods * ((b.res_groups + gpw - 1) / gpw) * NW < 8192) gpw = (gpw + 1) / 2;
+            gpw = (gpw + NW - 1) / NW * NW;                        // every wave of a workgroup gets a group
             const long parts = (b.res_groups + gpw - 1) / gpw;
             auto go = [&](auto exactc) {
                 hipLaunchKernelGGL((chs_resample_lanes_kernel<STEREO, decltype(exactc)::value>), dim3(static_cast<unsigned>(cgs * periods * parts)),
-                                   dim3(64 * kRW), 0, s, b.demod.p, b.dpitch, b.Hd, STEREO ? b.mixer.p : nullptr, b.mpitch, b.Hm, b.delay, b.res_table.p,
+                                   dim3(64 * kRW<STEREO>), 0, s, b.demod.p, b.dpitch, b.Hd, STEREO ? b.mixer.p : nullptr, b.mpitch, b.Hm, b.delay, b.res_table.p,
                                    b.res_top.p, b.res_groups, gpw, b.res_iters, p.audio_decim, p.audio_upsamp, periods, b.n_channels, d_audio, d_pcm,
                                    wrap, a_lo, b.n_audio);
             };
